@@ -1,0 +1,101 @@
+"""CPU: the oracle restatement reproduces the fixtures that oracle/make_golden.py recorded from the
+reference itself (losses.py, TFAM/models/AMO_CLIP.py, TFAM/data/dataset.py, HF CLIP from config,
+sklearn AP).  /root/reference is NOT needed here."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import indexing, metrics, student, tfam, vit
+from oracle import make_golden as mg
+from vimo_clip_amd import synth
+
+
+@pytest.mark.parametrize("c", mg.LOSS_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("mode", ["cosine", "mse"])
+def test_distillation_loss(golden, c, mode):
+    s, t = mg.loss_inputs(c)
+    s = s.requires_grad_(True)
+    l = student.distillation_loss(s, t, mode)
+    l.backward()
+    g = golden["losses"]
+    np.testing.assert_allclose(l.item(), g[f"{c['name']}/{mode}/loss"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(s.grad.numpy(), g[f"{c['name']}/{mode}/grad"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("c", mg.BCE_CASES, ids=lambda c: c["name"])
+def test_classification_loss(golden, c):
+    x, y = mg.bce_inputs(c)
+    x = x.requires_grad_(True)
+    l = student.classification_loss(x, y, c["pw"])
+    l.backward()
+    g = golden["losses"]
+    np.testing.assert_allclose(l.item(), g[f"{c['name']}/loss"], rtol=2e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g[f"{c['name']}/grad"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("c", mg.TFAM_CASES, ids=lambda c: c["name"])
+def test_tfam_logits(golden, c):
+    sd = synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"])
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    lo = tfam.amo_clip_forward(sd, rgb, mot, mr, mf, nhead=c["H"], use_pe=c["pe"], **mg.tfam_mode_kwargs(c["mode"]))
+    np.testing.assert_allclose(lo.numpy(), golden["tfam"][f"{c['name']}/logits"], atol=2e-5, rtol=0)
+
+
+def test_tfam_train_grads(golden):
+    c = mg.TFAM_CASES[0]
+    sd = {k: v.clone().requires_grad_(True) for k, v in
+          synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"]).items()}
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    y = synth.multi_hot_labels(c["seed"], "labels", c["B"], c["C"])
+    lo = tfam.amo_clip_forward(sd, rgb, mot, mr, mf, nhead=c["H"], use_pe=c["pe"], **mg.tfam_mode_kwargs(c["mode"]))
+    loss = tfam.bce_with_logits_mean(lo, y)
+    loss.backward()
+    g = golden["tfam"]
+    np.testing.assert_allclose(loss.item(), g[f"{c['name']}/train_loss"], rtol=1e-5)
+    for k in ("classifier.4.weight", "layers.0.ffn.0.bias", "layers.0.self_attn.in_proj_bias", "layers.0.norm_self.weight"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g[f"{c['name']}/grad/{k}"], atol=2e-6, rtol=1e-3)
+
+
+@pytest.mark.parametrize("c", [c for c in mg.VIT_CASES if c["name"] in ("tiny32", "tiny16", "tiny14", "b32")],
+                         ids=lambda c: c["name"])
+def test_vit_embeddings(golden, c):
+    H = synth.VIT_GEOMETRY[c["model"]][4]
+    sd = synth.vit_state_dict(c["model"], c["seed"], c["stress"])
+    y = vit.vit_forward(sd, vit.normalize_u8(mg.vit_pixels(c)), H)
+    ref = golden["vit"][f"{c['name']}/emb"]
+    np.testing.assert_allclose(y.numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()), rtol=0)
+
+
+def test_indexing(golden):
+    g = golden["indexing"]
+    for k in g.files:
+        parts = k.split("/")
+        if parts[0] == "sparse":
+            T, n = int(parts[1]), int(parts[2])
+            assert np.array_equal(indexing.sparse_sampling_indices(T, n).numpy(), g[k]), k
+        elif parts[0] == "frames":
+            total = int(parts[1])
+            mx = None if parts[2] == "None" else int(parts[2])
+            assert np.array_equal(indexing.sample_frame_indices(total, mx), g[k]), k
+    assert np.array_equal(indexing.pad_and_mask(list(g["collate/lens_rgb"])), g["collate/mask_rgb"])
+    assert np.array_equal(indexing.pad_and_mask(list(g["collate/lens_flow"])), g["collate/mask_flow"])
+
+
+def test_micro_ap(golden):
+    g = golden["metrics"]
+    for i in range(3):
+        N, C, quant = int(g[f"ap{i}/N"]), int(g[f"ap{i}/C"]), bool(g[f"ap{i}/quant"])
+        logits = synth.normal(50 + i, "ap_logits", (N, C), std=2.0)
+        if quant:
+            logits = torch.round(logits * 2) / 2
+        y = synth.multi_hot_labels(50 + i, "ap_labels", N, C).numpy()
+        ap = metrics.micro_average_precision(metrics.maybe_sigmoid(logits.numpy()), y)
+        assert abs(ap - float(g[f"ap{i}/value"])) < 1e-9
+
+
+def test_to_pil_wrap_identity():
+    # (v*255) mod 256 == (256 - v) mod 256 for every u8 value
+    v = torch.arange(256, dtype=torch.uint8)
+    w = vit.to_pil_wrap_u8(v)
+    assert torch.equal(w.to(torch.int64), (256 - v.to(torch.int64)) % 256)
+    assert np.array_equal((v.numpy().astype(np.float32) * 255).astype(np.int64) % 256, w.numpy())
