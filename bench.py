@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ViMoCLIP hot path on MI355X (contract: see the task prompt).
+
+A "step" = one pass of the hot path over one batch of synthetic input on every rank: the CLIP ViT-L/14
+frame encoder (BASELINE.json configs[1]) over B*T = 256 synthetic u8 224x224 frames, bf16 MFMA compute,
+fp32 accumulate; inputs are resident in HBM before the timed region.  Frames shard across ranks with no
+data-path collective (weak scaling: 256 frames per rank per step).
+
+    python bench.py [--gpus N --steps K --warmup W] [--model ViT-L/14 --frames 256 --dtype bf16]
+
+Prints ONE JSON line on rank 0.  `roofline` is the MFMA roofline of the dominant kernel family (the
+vmc_linear GEMMs): algorithmic FLOPs of every GEMM launch of K instrumented steps divided by the HIP-event
+duration of exactly those launches.  `cpu_baseline` times the CPU oracle (oracle/vit.py, fp32 PyTorch) on a
+bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/f16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def vit_flops_per_frame(name: str) -> float:
+    """2(N-1)*3p^2*D + L(6ND^2 + 4N^2 D + 2ND^2 + 4NDM) + 2DE."""
+    from vimo_clip_amd.synth import VIT_GEOMETRY
+    R, p, D, L, H, E = VIT_GEOMETRY[name]
+    N = (R // p) ** 2 + 1
+    M = 4 * D
+    return 2 * (N - 1) * 3 * p * p * D + L * (6 * N * D * D + 4 * N * N * D + 2 * N * D * D + 4 * N * D * M) + 2 * D * E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="ViT-L/14")
+    ap.add_argument("--frames", type=int, default=256, help="frames per rank per step (B*T)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from vimo_clip_amd import ops, synth
+    from vimo_clip_amd.clip_vit import VisionTransformer
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    model = VisionTransformer.from_name(args.model, compute_dtype=cdt).to(dev).eval()
+    sd = synth.vit_state_dict(args.model, seed=2)
+    model.load_state_dict(sd, strict=True)
+    model.frame_chunk = args.frames
+    R = model.input_resolution
+    frames = synth.randint_u8(1 + rank, "frames", (args.frames, 3, R, R)).to(dev)   # random, never zeros (DVFS)
+
+    def step():
+        return model.encode_frames_u8(frames)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    total_frames = args.frames * args.steps * world
+    fps = total_frames / elapsed
+    flops_frame = vit_flops_per_frame(args.model)
+
+    result = {
+        "metric": "CLIP frame-embeddings/sec (whole job; TFAM fused-clips/sec and mAP parity reported in DESIGN.md/tests)",
+        "value": round(fps, 2), "unit": "frame-embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"CLIP {args.model} frame encoder, B*T={args.frames} u8 224x224 frames per GPU per step "
+                               f"(BASELINE.json configs[1]), random-init weights, fp32 residual stream",
+                   "frames_per_gpu_per_step": args.frames, "parallelism": f"frame-sharded x{world}, no collective"},
+        "per_gpu_value": round(fps / world, 2),
+        "end_to_end_mfma_frac": round(fps / world * flops_frame / (MFMA_PEAK_TFLOPS * 1e12), 4),
+    }
+
+    if rank == 0:
+        # ---- roofline of the GEMM family: instrument every vmc_linear launch with HIP events --------
+        events = []
+        orig_linear = ops.linear
+
+        def timed_linear(a, w16, *pa, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_linear(a, w16, *pa, **kw)
+            e.record()
+            events.append((s, e, 2.0 * a.shape[0] * w16.shape[0] * w16.shape[1], a.shape[0] * w16.shape[0] >= 192 * 65536))
+            return r
+
+        ops.linear = timed_linear
+        try:
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            ops.linear = orig_linear
+        big = [(s.elapsed_time(e) * 1e-3, f) for s, e, f, is_big in events if is_big]
+        t_big = sum(t for t, _ in big)
+        f_big = sum(f for _, f in big)
+        achieved = f_big / t_big / 1e12 if big else 0.0
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_kernel<*,8,2,4> (vmc_linear 256x256x64 tiles)", "launches": len(big),
+            "avg_launch_ms": round(1e3 * t_big / max(1, len(big)), 4),
+            "note": "algorithmic FLOPs = 2*M*N*K (K incl. zero padding 588->640 of the patch GEMM) per launch",
+        }
+
+        if not args.no_cpu_baseline:
+            from oracle import vit as ovit
+            ncpu = os.cpu_count() or 1
+            torch.set_num_threads(ncpu)
+            nf = args.cpu_frames
+            pix = ovit.normalize_u8(frames[:nf].cpu())
+            H = model.heads
+            with torch.no_grad():
+                ovit.vit_forward(sd, pix[:1], H)                      # warm-up
+                t1 = time.perf_counter()
+                ovit.vit_forward(sd, pix, H)
+                dt_cpu = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": round(nf / dt_cpu, 3), "unit": "frame-embeddings/s", "cores": ncpu, "kind": "port",
+                                      "sample": f"oracle/vit.py fp32 PyTorch CPU, {nf} frames of the same workload, 1 pass"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * vmc.h — C ABI of libvmc.so, the MI355X (gfx950) kernels under the ViMoCLIP hot path.
+ *
+ * The reference (MarcosRodrigoT/VIMO-CLIP) has no FFI: its hot path sits behind Python nn.Module /
+ * function signatures and runs on stock PyTorch ATen ops.  Each entry point below replaces the ATen
+ * op site(s) named in its comment (paths relative to the reference checkout; SURVEY.md §2b ids K0..K16).
+ * The Python mirror of the reference interface (vimo_clip_amd/) calls these through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every buffer (inputs, outputs, workspace) is owned by the caller
+ *     (PyTorch's allocator); kernels never allocate, free or retain pointers;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no hidden streams,
+ *     no device synchronisation, safe under hipGraph capture;
+ *   - return 0 on success, a positive hipError_t on a HIP failure, a negative VMC_E_* on a bad argument;
+ *     never throws, never aborts;
+ *   - stateless and re-entrant; one process per GPU.
+ *   - "16-bit" tensors are bf16 or f16, selected per call by `dtype16` (VMC_BF16 / VMC_F16); all
+ *     reductions, softmax, LayerNorm statistics and GEMM accumulation are fp32.
+ */
+#ifndef VMC_H
+#define VMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VMC_F32 = 0, VMC_BF16 = 1, VMC_F16 = 2 };
+enum { VMC_ACT_NONE = 0, VMC_ACT_QUICKGELU = 1, VMC_ACT_GELU_ERF = 2, VMC_ACT_RELU = 3 };
+enum {
+  VMC_E_ARG = -1,       /* null pointer / non-positive size */
+  VMC_E_ALIGN = -2,     /* a stride or pointer violates the documented alignment */
+  VMC_E_SHAPE = -3,     /* unsupported shape (e.g. K % 64 != 0, head_dim not supported) */
+  VMC_E_DTYPE = -4
+};
+
+/* Library identity: returns the ABI version (1). */
+int vmc_abi_version(void);
+/* Human-readable message for a return code (static storage). */
+const char* vmc_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K0 — frame preprocess + patch extraction.
+ * Replaces the per-frame CPU loop  to_pil_image -> Resize/CenterCrop/ToTensor/Normalize
+ * (models/student_model.py:77-78) and PIL + CLIPImageProcessor (extract_embeddings.py:89-93) for frames
+ * that are already R x R (resize and crop are identities), and the im2col of visual.conv1
+ * (models/student_model.py:84).
+ *   frames  u8 [F,3,R,R] (NCHW, as FlowStudentModel.forward receives them)
+ *   patches 16-bit [F*g*g, kpad], g = R/p, column k = c*p*p + dy*p + dx, columns >= 3*p*p zero
+ *   value   ((wrap ? (256 - v) & 255 : v) / 255 - mean[c]) / std[c]   (wrap: SURVEY.md §7 quirk 1)
+ */
+int vmc_preprocess_patches_u8(const uint8_t* frames, void* patches, int F, int R, int p, int kpad,
+                              int wrap_quirk, int dtype16, void* stream);
+
+/* Same patch extraction for frames that are already normalised floats: `pixel_values` f32 [F,3,R,R], the
+ * argument of CLIPModel.get_image_features (extract_embeddings.py:91-94). */
+int vmc_patches_f32(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1/K3/K5/K6/K7/K9/K11-K14 — Linear layers:  C = epilogue(A @ W^T)   (MFMA, fp32 accumulate).
+ * Replaces nn.Linear / F.linear / conv1-as-GEMM / `x @ proj` op sites: visual.conv1, attn.in_proj,
+ * attn.out_proj, mlp.c_fc, mlp.c_proj, proj (OpenAI clip VisionTransformer, called at
+ * models/student_model.py:84), ResidualMLP.fc1/fc2 (models/student_model.py:33), classification_head
+ * (:55-59), nn.MultiheadAttention in/out projections, ffn.0/ffn.3, classifier.1/.4, projection_layer
+ * (TFAM/models/AMO_CLIP.py:19-29,84,86).
+ *   A [M,K] 16-bit row-major (row stride lda elements), W [N,K] 16-bit row-major (ldw)
+ *   v = act(acc + bias[n]);  C[orow, n] = alpha * v + res[rrow, n]
+ *   orow = out_row_group ? m + m / out_row_group + 1 : m      (patch rows -> token rows, class row skipped)
+ *   rrow = res_row_mod  ? m % res_row_mod : orow              (positional-embedding broadcast)
+ *   bias (f32 [N]) and res may be NULL; C and res are f32 or 16-bit (out_dtype / res_dtype).
+ * Requirements: K % 64 == 0, N % 4 == 0; lda, ldw % 8 == 0; ldc, ldres % 4 == 0; 16-byte aligned bases.
+ */
+int vmc_linear(const void* A, const void* W, const float* bias, const void* res, void* C,
+               int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+               int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+               int dtype16, void* stream);
+
+/* 16-bit 2-D transpose  out[c, r] = in[r, c]  (rows x cols, element strides ld_in / ld_out); used for
+ * the dgrad/wgrad operand layouts of K8 (autograd of F.linear, train.py:104). */
+int vmc_transpose16(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, void* stream);
+
+/* f32 -> 16-bit cast of a weight matrix [rows, cols] (+ optional transposed copy [cols, rows]); the
+ * 16-bit compute copies of the fp32 master parameters (models/student_model.py:45 keeps fp32). */
+int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows, int cols, int ld_out, int ld_out_t,
+                    int dtype16, void* stream);
+
+/* Column sums  out[n] = sum_m in[m, n]  (bias gradients, K8).  workspace: >= vmc_colsum_workspace_bytes. */
+size_t vmc_colsum_workspace_bytes(int M, int N);
+int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K2 — LayerNorm (eps inside sqrt, fp32 statistics).  Replaces ln_pre/ln_1/ln_2/ln_post of the CLIP
+ * ViT and norm_self/norm_cross/norm_ffn/classifier.0 (TFAM/models/AMO_CLIP.py:32-34,84).
+ *   x [rows, D] (row stride ldx; f32 or 16-bit), gamma/beta f32 [D]
+ *   y16 (16-bit, ld = D) and/or y32 (f32, ld = D): either may be NULL
+ *   mean/rstd f32 [rows]: optional saves for the backward
+ * Requirements: D % 4 == 0, D <= 4096.
+ */
+int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y16, float* y32,
+                      float* mean, float* rstd, int rows, int D, int ldx, float eps, int x_dtype,
+                      int dtype16, void* stream);
+/* dx [rows,D] (f32 or 16-bit per dx_dtype); dgamma/dbeta f32 [D] (overwritten).  dy f32 or 16-bit. */
+size_t vmc_layernorm_bwd_workspace_bytes(int rows, int D);
+int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                      int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K4 — ViT self-attention  softmax(Q K^T / sqrt(dh)) V, no mask, head_dim 64 (MFMA, K/V tile in LDS).
+ * Replaces the SDPA inside nn.MultiheadAttention of every CLIP residual block.
+ *   qkv 16-bit [F*N, 3*D] packed as the in_proj output: columns [0,D)=Q, [D,2D)=K, [2D,3D)=V, head h at
+ *   columns h*64..h*64+63;  out 16-bit [F*N, D].   D = H*64, N <= 288.
+ *   lse f32 [F, H, N] optional (log-sum-exp of the scaled scores, saved for the backward).
+ */
+int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int F, int N, int H, int dtype16,
+                          void* stream);
+
+/* K4/K11/K12 generic masked attention (fp32 math), any head_dim <= 128 with head_dim % 8 == 0.
+ * Replaces F.multi_head_attention_forward's core (q*dh^-1/2, key_padding_mask -> -inf, softmax, @V)
+ * for the TFAM self/cross attention (TFAM/models/AMO_CLIP.py:39-45) and serves as the backward's
+ * forward-recompute reference.
+ *   q  16-bit, element (b, t, h, d) at q[(b*Tq + t)*ldq + h*dh + d];  k, v likewise with Tk, ldk, ldv
+ *   key_mask u8 [B, Tk], 1 = attend, 0 = padding (the reference's mask_rgb/mask_flow), may be NULL
+ *   out 16-bit [(b*Tq+t)*ldo + h*dh + d];  lse f32 [B,H,Tq] optional.
+ *   A query row whose keys are all masked yields NaN, as torch does.
+ */
+int vmc_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* out,
+                      float* lse, int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
+                      int dtype16, void* stream);
+/* Backward of the above (autograd of the MHA core, train.py:104 / TFAM/train_and_eval.py:82): dq, dk, dv
+ * 16-bit with their own row strides, fully overwritten.  workspace >= vmc_attention_bwd_workspace_bytes. */
+size_t vmc_attention_bwd_workspace_bytes(int B, int H, int Tq);
+int vmc_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, const void* out,
+                      const void* dout, const float* lse, void* dq, void* dk, void* dv,
+                      int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
+                      int lddq, int lddk, int lddv, void* workspace, size_t workspace_bytes, int dtype16,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Small element-wise / pooling pieces.
+ */
+/* rows[f*row_stride + 0..D) = a[0..D) + b[0..D)  for f < F  (class token + positional_embedding[0]). */
+int vmc_set_class_rows(void* x, const float* a, const float* b, int F, int D, size_t row_stride, int x_dtype,
+                       int dtype16, void* stream);
+/* y = act(x) and dx = dy * act'(x) on [n] elements (training path keeps pre-activations). */
+int vmc_act_fwd(const void* x, void* y, size_t n, int act, int dtype16, void* stream);
+int vmc_act_bwd(const void* x, const void* dy, void* dx, size_t n, int act, int dtype16, void* stream);
+/* out[b, :] = mean_t x[b, t, :]  over ALL T rows (TFAM/models/AMO_CLIP.py:170 pools padded rows too;
+ * models/student_model.py:93).  x f32 or 16-bit, out16 and/or out32. */
+int vmc_mean_pool(const void* x, void* out16, float* out32, int B, int T, int D, int x_dtype, int dtype16,
+                  void* stream);
+/* x[b,t,:] += pe[t,:]  sinusoidal positional encoding of TFAM/models/AMO_CLIP.py:88-97 (f32 in place). */
+int vmc_add_sinusoidal_pe(float* x, int B, int T, int D, void* stream);
+/* y = a + alpha * b elementwise, f32. */
+int vmc_axpby_f32(const float* a, const float* b, float* y, size_t n, float alpha, float beta, void* stream);
+/* f32 <-> 16-bit casts on flat arrays. */
+int vmc_cast_f32_to_16(const float* x, void* y, size_t n, int dtype16, void* stream);
+int vmc_cast_16_to_f32(const void* x, float* y, size_t n, int dtype16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K10 — losses (forward value + gradient in one pass, fp32).
+ * Cosine / MSE distillation: losses.py:5-44.   student, teacher f32 [rows, E] (teacher row stride ldt
+ * covers the `rgb_emb[:, :-1]` slice of train.py:98 via teacher_rows_per_clip / teacher_clip_stride).
+ *   loss f32[1] (overwritten), dstudent f32 [rows,E] = d loss / d student (may be NULL).
+ */
+size_t vmc_loss_workspace_bytes(int rows);
+int vmc_distill_loss(const float* student, const float* teacher, float* loss, float* dstudent,
+                     int rows, int E, int rows_per_clip, size_t teacher_clip_stride, int mode_cosine,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* BCE-with-logits, pos_weight = pw*y + 1 (losses.py:59-67; pw < 0 means "None" -> weight 1; also
+ * nn.BCEWithLogitsLoss of TFAM/train_and_eval.py:58).  logits/targets f32 [n]; mean over n. */
+int vmc_bce_loss(const float* logits, const float* targets, float* loss, float* dlogits, int n, float pos_weight,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K15 — fused Adam / AdamW over one flat fp32 buffer (train.py:66; TFAM/train_and_eval.py:53).
+ *   decoupled_wd = 1: p *= 1 - lr*wd first (AdamW); 0: g += wd*p (Adam L2).
+ *   grad_scale multiplies g first (clip_grad_norm_ coefficient / DDP averaging).
+ */
+int vmc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int decoupled_wd, int step, float grad_scale, void* stream);
+/* sum of squares of a flat f32 buffer, accumulated (+=) into out[0] (global grad norm). */
+int vmc_sumsq(const float* x, size_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMC_H */

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports exactly what include/vmc.h declares;
+the ctypes table mirrors the header (argument counts).  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "vmc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(vmc_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[m.group(1)] = n
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from vimo_clip_amd import _lib
+    fns = _header_functions()
+    assert len(fns) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in fns:
+        assert hasattr(lib, name), f"{name} declared in include/vmc.h but not exported by libvmc.so"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vmc_\w+)", nm))
+    assert exported == set(fns), f"header/library mismatch: {exported ^ set(fns)}"
+
+
+def test_ctypes_table_matches_header():
+    from vimo_clip_amd import _lib
+    fns = _header_functions()
+    assert set(_lib.SIGNATURES) == set(fns)
+    for name, n in fns.items():
+        assert len(_lib.SIGNATURES[name][1]) == n, f"{name}: header has {n} args, ctypes table {len(_lib.SIGNATURES[name][1])}"
+
+
+def test_error_strings_and_version():
+    from vimo_clip_amd import _lib
+    assert _lib.lib.vmc_abi_version() == 1
+    assert b"alignment" in _lib.lib.vmc_error_string(-2)
+    assert _lib.lib.vmc_error_string(0) == b"success"
+
+
+def test_gfx950_code_object_present():
+    from vimo_clip_amd import _lib
+    out = subprocess.run(["strings", "-n", "6", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_cpu_fallback_for_host_tensors():
+    import pytest
+    import torch
+    from vimo_clip_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))

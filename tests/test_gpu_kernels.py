@@ -1,0 +1,217 @@
+"""GPU: every libvmc kernel against a plain PyTorch fp32 CPU reference of the same op (called through
+the C ABI via vimo_clip_amd.ops).  Integer-valued operands make the MFMA GEMM checks bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DT16 = [torch.bfloat16, torch.float16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from vimo_clip_amd import ops as _ops
+    return _ops
+
+
+def _ints(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+# ---------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [
+    (256, 256, 64), (512, 1024, 128),          # whole 256x256 tiles (identity-free, asymmetric W)
+    (65792 // 16, 1024, 1024),                 # 4112 rows: 128x128 config with a ragged last row tile
+    (3333, 4096, 128), (3100, 3072, 64),       # 256x256 config (>= 192 tiles), ragged M, odd and single K tile
+    (300, 140, 64), (50, 768, 192), (8, 384, 768), (129, 2304, 768), (1000, 64, 3072), (16448, 256, 640),
+])
+def test_linear_exact_integers(ops, dtype, M, N, K):
+    a = _ints((M, K), -3, 3, 1)
+    w = _ints((N, K), -2, 2, 2)
+    w[:, 0] += torch.arange(N).float() % 5      # asymmetric in n
+    a[:, 1] += torch.arange(M).float() % 3      # asymmetric in m
+    ref = a @ w.t()
+    assert ref.abs().max() < 2 ** 24
+    out = ops.linear(a.to(DEV, dtype), w.to(DEV, dtype), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref), f"max diff {(out.cpu() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+@pytest.mark.parametrize("res_f32,out_f32", [(True, True), (False, False), (True, False)])
+def test_linear_epilogue(ops, dtype, act, res_f32, out_f32):
+    M, N, K = 333, 200, 128
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.2).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(torch.float32 if res_f32 else dtype)
+    z = a.float() @ w.float().t() + bias
+    if act == 1:
+        z = z * torch.sigmoid(1.702 * z)
+    elif act == 2:
+        z = torch.nn.functional.gelu(z)
+    elif act == 3:
+        z = torch.relu(z)
+    ref = 0.5 * z + res.float()
+    out = ops.linear(a.to(DEV), w.to(DEV), bias=bias.to(DEV), res=res.to(DEV), act=act, alpha=0.5,
+                     out_dtype=torch.float32 if out_f32 else dtype)
+    tol = 2e-5 if out_f32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    torch.testing.assert_close(out.float().cpu(), ref, atol=tol * max(1.0, ref.abs().max().item()), rtol=tol)
+
+
+def test_linear_patch_rows_and_posemb(ops):
+    # out_row_group / res_row_mod: patch rows -> token rows with positional-embedding broadcast (K1)
+    F, g2, D, K = 3, 16, 128, 64
+    dtype = torch.bfloat16
+    a = _ints((F * g2, K), -2, 2, 7)
+    w = _ints((D, K), -2, 2, 8)
+    pos = _ints((g2 + 1, D), -4, 4, 9)
+    x = torch.full((F * (g2 + 1), D), -77.0, device=DEV)
+    ops.linear(a.to(DEV, dtype), w.to(DEV, dtype), res=pos.to(DEV)[1:], out=x, out_row_group=g2, res_row_mod=g2)
+    ref = torch.full((F, g2 + 1, D), -77.0)
+    ref[:, 1:] = (a @ w.t()).view(F, g2, D) + pos[1:]
+    assert torch.equal(x.cpu().view(F, g2 + 1, D), ref)
+
+
+def test_linear_bad_args(ops):
+    a = torch.zeros(8, 60, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(16, 60, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="libvmc linear failed"):
+        ops.linear(a, w)
+
+
+# ---------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,D,xf32", [(1000, 1024, True), (77, 768, False), (5, 128, True), (4099, 512, False)])
+def test_layernorm_fwd(ops, dtype, rows, D, xf32):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, D, generator=g) * 3 + 1).to(torch.float32 if xf32 else dtype)
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gamma, beta, 1e-5)
+    y16, y32, mean, rstd = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), dtype, out16=True, out32=True, save_stats=True)
+    torch.testing.assert_close(y32.cpu(), ref, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(y16.float().cpu(), ref.to(dtype).float(), atol=2e-2 if dtype == torch.bfloat16 else 2e-3, rtol=1e-2)
+    torch.testing.assert_close(mean.cpu(), x.float().mean(-1), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), (x.float().var(-1, unbiased=False) + 1e-5).rsqrt(), atol=1e-5, rtol=1e-4)
+
+
+def test_layernorm_strided_rows_inplace(ops):
+    # CLS-row gather (ldx = N*D) and in-place fp32 (ln_pre)
+    F, N, D = 6, 5, 256
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(F * N, D, generator=g)
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xd = x.to(DEV)
+    y16, *_ = ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), torch.float16, rows=F, ldx=N * D)
+    ref = torch.nn.functional.layer_norm(x.view(F, N, D)[:, 0], (D,), gamma, beta, 1e-5)
+    torch.testing.assert_close(y16.float().cpu(), ref, atol=3e-3, rtol=3e-3)
+    ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), torch.float16, out16=False, out32=True, y32=xd)
+    torch.testing.assert_close(xd.cpu(), torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5), atol=2e-5, rtol=2e-5)
+
+
+# ---------------------------------------------------------------- attention
+def _attn_ref(q, k, v, mask=None):
+    dh = q.shape[-1]
+    s = (q * dh ** -0.5) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("F,N,H", [(3, 257, 2), (2, 50, 12), (2, 197, 3), (5, 17, 2), (1, 5, 2)])
+def test_attention_vit(ops, dtype, F, N, H):
+    D = H * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(F * N, 3 * D, generator=g).to(dtype)
+    qkv[3 % (F * N), D:D + 64] *= 6.0                      # a spiky key: softmax far from uniform
+    q, k, v = [t.float().view(F, N, H, 64).transpose(1, 2) for t in qkv.split(D, dim=1)]
+    ref = _attn_ref(q, k, v).transpose(1, 2).reshape(F * N, D)
+    out, lse = ops.attention_vit(qkv.to(DEV), F, N, H, want_lse=True)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    torch.testing.assert_close(out.float().cpu(), ref, atol=tol, rtol=tol)
+    lse_ref = torch.logsumexp((q * 0.125) @ k.transpose(-1, -2), -1)
+    torch.testing.assert_close(lse.cpu(), lse_ref, atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(4, 8, 16, 15, 96), (3, 8, 16, 16, 64), (2, 8, 40, 39, 64), (2, 2, 100, 257, 64)])
+def test_attention_generic_masked(ops, dtype, B, H, Tq, Tk, dh):
+    D = H * dh
+    g = torch.Generator().manual_seed(12)
+    q = torch.randn(B * Tq, D, generator=g).to(dtype)
+    kv = torch.randn(B * Tk, 2 * D, generator=g).to(dtype)
+    lens = torch.randint(1, Tk + 1, (B,), generator=g)
+    lens[0] = Tk
+    mask = torch.arange(Tk)[None, :] < lens[:, None]
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    out, lse = ops.attention(qd, kvd[:, :D], kvd[:, D:], mask.to(torch.uint8).to(DEV), B, H, Tq, Tk, dh, want_lse=True)
+    qf = q.float().view(B, Tq, H, dh).transpose(1, 2)
+    kf = kv[:, :D].float().view(B, Tk, H, dh).transpose(1, 2)
+    vf = kv[:, D:].float().view(B, Tk, H, dh).transpose(1, 2)
+    ref = _attn_ref(qf, kf, vf, mask).transpose(1, 2).reshape(B * Tq, D)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(out.float().cpu(), ref, atol=tol, rtol=tol)
+
+
+def test_attention_vit_matches_generic(ops):
+    F, N, H = 2, 257, 4
+    D = H * 64
+    qkv = torch.randn(F * N, 3 * D, generator=torch.Generator().manual_seed(13)).to(torch.float16).to(DEV)
+    a, _ = ops.attention_vit(qkv, F, N, H)
+    b, _ = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], None, F, H, N, N, 64)
+    torch.testing.assert_close(a.float(), b.float(), atol=3e-3, rtol=3e-3)
+
+
+# ---------------------------------------------------------------- preprocess / misc
+@pytest.mark.parametrize("R,p", [(224, 14), (224, 32), (224, 16), (64, 16)])
+@pytest.mark.parametrize("wrap", [False, True])
+def test_preprocess_patches(ops, R, p, wrap):
+    from oracle import vit as ovit
+    F = 2
+    g = torch.Generator().manual_seed(21)
+    fr = torch.randint(0, 256, (F, 3, R, R), generator=g, dtype=torch.uint8)
+    src = ovit.to_pil_wrap_u8(fr) if wrap else fr
+    pix = ovit.normalize_u8(src)
+    gg = R // p
+    ref = pix.view(F, 3, gg, p, gg, p).permute(0, 2, 4, 1, 3, 5).reshape(F * gg * gg, 3 * p * p)
+    out = ops.preprocess_patches_u8(fr.to(DEV), p, torch.float16, wrap).float().cpu()
+    k = 3 * p * p
+    assert out.shape[1] % 64 == 0 and torch.all(out[:, k:] == 0)
+    torch.testing.assert_close(out[:, :k], ref.to(torch.float16).float(), atol=1e-3, rtol=1e-3)
+    out2 = ops.patches_f32(pix.to(DEV), p, torch.float16).float().cpu()
+    assert torch.equal(out2[:, :k], ref.to(torch.float16).float())
+
+
+def test_transpose_colsum_cast_pool_pe(ops):
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(203, 77, generator=g).to(torch.bfloat16)
+    assert torch.equal(ops.transpose16(x.to(DEV)).cpu(), x.t().contiguous())
+    y = torch.randn(1030, 140, generator=g)
+    torch.testing.assert_close(ops.colsum(y.to(DEV)).cpu(), y.sum(0), atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(ops.colsum(y.to(torch.float16).to(DEV)).cpu(), y.to(torch.float16).float().sum(0), atol=1e-3, rtol=1e-4)
+    w = torch.randn(70, 588, generator=g)
+    c = ops.cast_weight(w.to(DEV), torch.bfloat16, pad_k=True)
+    assert c.shape == (70, 640) and torch.equal(c[:, :588].cpu(), w.to(torch.bfloat16)) and torch.all(c[:, 588:] == 0)
+    ct = ops.cast_weight(w.to(DEV), torch.float16, transposed=True)
+    assert torch.equal(ct.cpu(), w.t().contiguous().to(torch.float16))
+    z = torch.randn(3, 16, 768, generator=g)
+    _, p32 = ops.mean_pool(z.to(DEV), 3, 16, 768, torch.bfloat16, out16=False, out32=True)
+    torch.testing.assert_close(p32.cpu(), z.mean(1), atol=1e-6, rtol=1e-5)
+    from oracle import tfam
+    e = torch.zeros(2, 40, 512, device=DEV)
+    ops.add_sinusoidal_pe_(e)
+    torch.testing.assert_close(e.cpu()[0], tfam.positional_encoding(40, 512), atol=2e-5, rtol=0)
+    for act in (1, 2, 3):
+        v = torch.randn(1000, generator=g).to(torch.float16)
+        ref = {1: v.float() * torch.sigmoid(1.702 * v.float()), 2: torch.nn.functional.gelu(v.float()), 3: torch.relu(v.float())}[act]
+        torch.testing.assert_close(ops.act_fwd(v.to(DEV), act).float().cpu(), ref, atol=2e-3, rtol=2e-3)

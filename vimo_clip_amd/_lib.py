@@ -1,0 +1,96 @@
+"""ctypes binding of libvmc.so (include/vmc.h).  There is NO fallback: if the library is missing the
+import fails loudly, and every compute entry point raises on a non-zero return code."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvmc.so")
+
+F32, BF16, F16 = 0, 1, 2
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_RELU = 0, 1, 2, 3
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/vmc.h one to one (tests/test_abi.py checks both against
+# the header and the built library).
+SIGNATURES = {
+    "vmc_abi_version": (I, []),
+    "vmc_error_string": (c_char_p, [I]),
+    "vmc_preprocess_patches_u8": (I, [P, P, I, I, I, I, I, I, P]),
+    "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
+    "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
+    "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
+    "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),
+    "vmc_colsum_workspace_bytes": (Z, [I, I]),
+    "vmc_colsum": (I, [P, P, I, I, I, I, P, Z, P]),
+    "vmc_layernorm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
+    "vmc_layernorm_bwd_workspace_bytes": (Z, [I, I]),
+    "vmc_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "vmc_attention_vit_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "vmc_attention_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_attention_bwd_workspace_bytes": (Z, [I, I, I]),
+    "vmc_attention_bwd": (I, [P] * 10 + [I] * 12 + [P, Z, I, P]),
+    "vmc_set_class_rows": (I, [P, P, P, I, I, Z, I, I, P]),
+    "vmc_act_fwd": (I, [P, P, Z, I, I, P]),
+    "vmc_act_bwd": (I, [P, P, P, Z, I, I, P]),
+    "vmc_mean_pool": (I, [P, P, P, I, I, I, I, I, P]),
+    "vmc_add_sinusoidal_pe": (I, [P, I, I, I, P]),
+    "vmc_axpby_f32": (I, [P, P, P, Z, F, F, P]),
+    "vmc_cast_f32_to_16": (I, [P, P, Z, I, P]),
+    "vmc_cast_16_to_f32": (I, [P, P, Z, I, P]),
+    "vmc_loss_workspace_bytes": (Z, [I]),
+    "vmc_distill_loss": (I, [P, P, P, P, I, I, I, Z, I, P, Z, P]),
+    "vmc_bce_loss": (I, [P, P, P, P, I, F, P, Z, P]),
+    "vmc_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, I, F, P]),
+    "vmc_sumsq": (I, [P, Z, P, P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C vimo_clip_amd/csrc`). There is no CPU/PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vmc_abi_version() != 1:
+        raise ImportError("libvmc.so ABI version mismatch; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.vmc_error_string(int(rc))
+        raise RuntimeError(f"libvmc {what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def dt(t) -> int:
+    try:
+        return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype for libvmc: {t}") from None
+
+
+def ptr(t) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libvmc kernels need device (HIP) tensors; there is no CPU path")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

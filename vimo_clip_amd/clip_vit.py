@@ -1,0 +1,202 @@
+"""CLIP ViT image encoder on the libvmc HIP kernels.
+
+Drop-in for the two third-party encoders the reference calls:
+  * OpenAI ``clip`` ``model.visual`` (models/student_model.py:44-48,84): ``VisionTransformer`` keeps the
+    parameter names (``conv1.weight, class_embedding, positional_embedding, ln_pre.*,
+    transformer.resblocks.{i}.{ln_1,attn.in_proj_weight,attn.in_proj_bias,attn.out_proj,ln_2,mlp.c_fc,
+    mlp.c_proj}, ln_post.*, proj``) so reference checkpoints load with ``strict=True`` (inference.py:86),
+    and the attributes ``output_dim`` / ``input_resolution`` (models/student_model.py:49).
+  * HF ``CLIPModel.get_image_features`` (extract_embeddings.py:94): ``CLIPImageEncoder``.
+
+Data layout in HBM (F frames, N = g*g+1 tokens, width D):
+  patches [F*g*g, kpad] 16-bit  ->  x [F*N, D] residual stream (fp32 by default)  ->  per block:
+  h [F*N, D] 16-bit (LayerNorm out), qkv [F*N, 3D] 16-bit, o [F*N, D] 16-bit, u [F*N, 4D] 16-bit.
+All GEMMs are vmc_linear (bf16/f16 MFMA, fp32 accumulate) with bias / QuickGELU / residual /
+positional-embedding epilogues fused; there is no PyTorch compute on this path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .synth import VIT_GEOMETRY
+
+
+class _LN(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _Lin(nn.Module):
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d_out, d_in))
+        self.bias = nn.Parameter(torch.zeros(d_out))
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Lin(d, d)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d, heads):
+        super().__init__()
+        self.attn = _Attn(d)
+        self.ln_1 = _LN(d)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", _Lin(d, 4 * d)), ("c_proj", _Lin(4 * d, d))]))
+        self.ln_2 = _LN(d)
+        self.heads = heads
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class _Conv(nn.Module):
+    def __init__(self, d, p):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d, 3, p, p))
+
+
+class VisionTransformer(nn.Module):
+    """OpenAI-clip ``VisionTransformer`` parameter surface; forward runs on libvmc."""
+
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int,
+                 compute_dtype: torch.dtype = torch.bfloat16, residual_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        if width != heads * 64:
+            raise ValueError("CLIP ViT geometries have head_dim 64")
+        self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
+        self.width, self.layers, self.heads = width, layers, heads
+        self.conv1 = _Conv(width, patch_size)
+        scale = width ** -0.5
+        g = input_resolution // patch_size
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn(g * g + 1, width))
+        self.ln_pre = _LN(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = _LN(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.compute_dtype = compute_dtype
+        self.residual_dtype = residual_dtype
+        self._w16 = {}          # name -> (param version, 16-bit copy)
+        self.frame_chunk = 256  # frames per pass (bounds activation memory; F*N*4D*2 B for the MLP buffer)
+        self._init_weights()
+
+    @classmethod
+    def from_name(cls, name: str, **kw):
+        R, p, D, L, H, E = VIT_GEOMETRY[name]
+        return cls(R, p, D, L, H, E, **kw)
+
+    def _init_weights(self):
+        D, L = self.width, self.layers
+        proj_std, attn_std, fc_std = (D ** -0.5) * ((2 * L) ** -0.5), D ** -0.5, (2 * D) ** -0.5
+        nn.init.normal_(self.conv1.weight, std=(3 * self.patch_size ** 2) ** -0.5)
+        for blk in self.transformer.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(blk.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
+
+    # ---- 16-bit compute copies of the fp32 master weights -------------------------------------------
+    def w16(self, name: str, param: torch.Tensor, transposed=False, pad_k=False) -> torch.Tensor:
+        key = (name, self.compute_dtype, transposed)
+        hit = self._w16.get(key)
+        if hit is not None and hit[0] == param._version and hit[1].device == param.device:
+            return hit[1]
+        w = ops.cast_weight(param, self.compute_dtype, transposed=transposed, pad_k=pad_k)
+        self._w16[key] = (param._version, w)
+        return w
+
+    def invalidate_weight_cache(self):
+        self._w16.clear()
+
+    # ---- inference forward ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def _encode_patches(self, patches: torch.Tensor, F: int) -> torch.Tensor:
+        dt16, D, H = self.compute_dtype, self.width, self.heads
+        g = self.input_resolution // self.patch_size
+        g2, N = g * g, g * g + 1
+        dev = patches.device
+        x = torch.empty((F * N, D), dtype=self.residual_dtype, device=dev)
+        pos = self.positional_embedding.detach()
+        # K1: patch GEMM, epilogue adds positional_embedding[1 + patch] and scatters into token rows
+        ops.linear(patches, self.w16("conv1", self.conv1.weight, pad_k=True), res=pos[1:], out=x,
+                   out_row_group=g2, res_row_mod=g2)
+        ops.set_class_rows(x, self.class_embedding.detach(), pos[0], F, D, N * D, dt16)
+        xf32 = self.residual_dtype == torch.float32
+        # ln_pre in place on the residual stream
+        if xf32:
+            ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias, dt16, out16=False, out32=True, y32=x)
+        else:
+            self._ln_inplace16(x, self.ln_pre)
+        for i, blk in enumerate(self.transformer.resblocks):
+            pre = f"blk{i}."
+            h, *_ = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, dt16)
+            qkv = ops.linear(h, self.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
+            o, _ = ops.attention_vit(qkv, F, N, H)
+            del qkv
+            ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x, out=x)
+            h, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16)
+            u = ops.linear(h, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+            ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=x, out=x)
+            del u, h, o
+        cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
+        return ops.linear(cls, self.w16("proj", self.proj, transposed=True), out_dtype=torch.float32)
+
+    def _ln_inplace16(self, x, ln):
+        y, *_ = ops.layernorm(x, ln.weight, ln.bias, self.compute_dtype)
+        x.copy_(y)   # device-to-device copy (memory plumbing); only taken for a 16-bit residual stream
+
+    @torch.no_grad()
+    def encode_frames_u8(self, frames_u8: torch.Tensor, wrap_quirk: bool = False) -> torch.Tensor:
+        """[F,3,R,R] u8 -> [F,E] f32.  Fuses the CLIP normalisation into the patch extraction (K0)."""
+        outs = []
+        for s in range(0, frames_u8.shape[0], self.frame_chunk):
+            fr = frames_u8[s:s + self.frame_chunk]
+            patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap_quirk)
+            outs.append(self._encode_patches(patches, fr.shape[0]))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def encode_pixel_values(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """[F,3,R,R] normalised floats -> [F,E] f32 (the ``visual_encoder(x)`` call of student_model.py:84)."""
+        outs = []
+        for s in range(0, pixel_values.shape[0], self.frame_chunk):
+            pv = pixel_values[s:s + self.frame_chunk]
+            outs.append(self._encode_patches(ops.patches_f32(pv, self.patch_size, self.compute_dtype), pv.shape[0]))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd_vit import vit_forward_train
+            return vit_forward_train(self, x)
+        if x.dtype == torch.uint8:
+            return self.encode_frames_u8(x)
+        return self.encode_pixel_values(x)
+
+
+class CLIPImageEncoder(nn.Module):
+    """The slice of HF ``CLIPModel`` the extractor uses (extract_embeddings.py:17,94):
+    ``get_image_features(pixel_values) -> [F, E]`` tensor (transformers 4.53.2 semantics)."""
+
+    def __init__(self, clip_model_name: str = "ViT-B/16", compute_dtype=torch.bfloat16, residual_dtype=torch.float32):
+        super().__init__()
+        self.visual = VisionTransformer.from_name(clip_model_name, compute_dtype=compute_dtype,
+                                                  residual_dtype=residual_dtype)
+
+    @torch.no_grad()
+    def get_image_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        return self.visual.encode_pixel_values(pixel_values)

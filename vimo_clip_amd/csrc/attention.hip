@@ -1,0 +1,362 @@
+// Attention kernels (gfx950).
+//   vmc_attention_vit_fwd : CLIP ViT self-attention, head_dim 64, no mask — MFMA, whole K/V head in LDS.
+//   vmc_attention_fwd/bwd : generic masked attention in fp32 (TFAM self/cross attention; also the
+//                           training backward of the ViT blocks).
+#include "common.h"
+
+// ==================================================================================================
+// ViT forward.  One workgroup = one (frame, head); 4 waves; each wave owns 16-query tiles.
+//   S^T = K Q^T  (mfma(K_frag, Q_frag)): lane (r = lane&15, q = lane>>4) holds, for query r, the keys
+//   16 nt + 4 q + j  -> the whole softmax row of a query sits in 4 lanes (2 shuffles per reduction) and
+//   the exponentiated accumulators are directly the B operand of O^T = V^T P^T with the k-slots
+//   permuted (tile_index.h attn_pv_key); V^T fragments come from ds_read_b64_tr_b16.
+// ==================================================================================================
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKEYS = 16 * NT;
+  char* const k_lds = smem;
+  char* const v_lds = smem + NKEYS * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int f = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * 64;
+  const size_t ld = (size_t)3 * D;
+  const uint16_t* base = qkv + (size_t)f * N * ld + h * 64;
+
+  // ---- stage K and V (zero rows for padded keys) ----
+  for (int idx = tid; idx < NKEYS * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (row < N) {
+      const uint16_t* p = base + (size_t)row * ld + c * 8;
+      kv = *(const uint4*)(p + D);
+      vv = *(const uint4*)(p + 2 * D);
+    }
+    *(uint4*)(k_lds + lds_off_x(row, c)) = kv;
+    *(uint4*)(v_lds + lds_off_v(row, c)) = vv;
+  }
+  __syncthreads();
+
+  const float c2 = scale * 1.4426950408889634f;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = qt * 16 + r;
+    const int qrow_ld = min(qrow, N - 1);
+    uint4 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const uint4*)(base + (size_t)qrow_ld * ld + (4 * kk + q) * 8);
+
+    f32x4 s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4 kf = *(const uint4*)(k_lds + lds_off_x(16 * nt + r, 4 * kk + q));
+        s[nt] = T::mfma16(kf, qf[kk], s[nt]);
+      }
+    }
+    // ---- softmax over the row (keys >= N masked) ----
+    float m = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = 16 * nt + 4 * q + j;
+        if (key >= N) s[nt][j] = -INFINITY;
+        m = fmaxf(m, s[nt][j]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = __builtin_amdgcn_exp2f((s[nt][j] - m) * c2);
+        s[nt][j] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
+
+    // ---- O^T = V^T P^T ----
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NT / 2; ++ks) {
+      uint4 pf;
+      pf.x = pack2<T>(s[2 * ks][0], s[2 * ks][1]);
+      pf.y = pack2<T>(s[2 * ks][2], s[2 * ks][3]);
+      pf.z = pack2<T>(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+      pf.w = pack2<T>(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        // 4-key x 16-column blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block
+        const int key0 = 32 * ks + 4 * q + (r >> 2);
+        const int chunk = 2 * dt + ((r & 3) >> 1);
+        const int half = (r & 1) * 8;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + lds_off_v(key0, chunk) + half));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + lds_off_v(key0 + 16, chunk) + half));
+        uint4 vf;
+        const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
+        vf.x = a.x; vf.y = a.y; vf.z = b.x; vf.w = b.y;
+        o[dt] = T::mfma16(vf, pf, o[dt]);
+      }
+    }
+    if (qrow < N) {
+      uint16_t* orow = out + ((size_t)f * N + qrow) * D + h * 64 + 4 * q;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *(uint2*)(orow + 16 * dt) = make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
+    }
+  }
+}
+
+template <typename T, int NT>
+static int launch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t stream) {
+  auto kern = attn_vit_kernel<T, NT>;
+  constexpr int LDS = 16 * NT * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(F * H), dim3(256), LDS, stream, (const uint16_t*)qkv, (uint16_t*)out, lse, N, H, 0.125f);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int dispatch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t s) {
+  if (N <= 32) return launch_vit<T, 2>(qkv, out, lse, F, N, H, s);
+  if (N <= 64) return launch_vit<T, 4>(qkv, out, lse, F, N, H, s);
+  if (N <= 128) return launch_vit<T, 8>(qkv, out, lse, F, N, H, s);
+  if (N <= 224) return launch_vit<T, 14>(qkv, out, lse, F, N, H, s);
+  if (N <= 288) return launch_vit<T, 18>(qkv, out, lse, F, N, H, s);
+  return VMC_E_SHAPE;
+}
+
+extern "C" int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int F, int N, int H, int dtype16, void* stream) {
+  if (!qkv || !out || F <= 0 || N <= 0 || H <= 0) return VMC_E_ARG;
+  if (((uintptr_t)qkv | (uintptr_t)out) & 15) return VMC_E_ALIGN;
+  if (dtype16 == VMC_BF16) return dispatch_vit<BF16>(qkv, out, lse, F, N, H, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return dispatch_vit<F16>(qkv, out, lse, F, N, H, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+// ==================================================================================================
+// Generic masked attention, fp32 math.  One wave per (batch, head, query).  Scores live in LDS.
+// ==================================================================================================
+#define ATT_MAX_TK 2048
+#define ATT_MAX_DH 128
+
+template <typename T>
+__device__ inline float dot16(const uint16_t* __restrict__ a16, const float* __restrict__ bf, int dh) {
+  float acc = 0.f;
+  for (int d = 0; d < dh; d += 8) {
+    const uint4 w = *(const uint4*)(a16 + d);
+    float x0, x1;
+    unpack2<T>(w.x, x0, x1); acc += x0 * bf[d] + x1 * bf[d + 1];
+    unpack2<T>(w.y, x0, x1); acc += x0 * bf[d + 2] + x1 * bf[d + 3];
+    unpack2<T>(w.z, x0, x1); acc += x0 * bf[d + 4] + x1 * bf[d + 5];
+    unpack2<T>(w.w, x0, x1); acc += x0 * bf[d + 6] + x1 * bf[d + 7];
+  }
+  return acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) attn_generic_fwd(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                       const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
+                                                       uint16_t* __restrict__ op, float* __restrict__ lse, int H, int Tq,
+                                                       int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale) {
+  __shared__ float qs[ATT_MAX_DH];
+  __shared__ float ps[ATT_MAX_TK];
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x % Tq, h = (blockIdx.x / Tq) % H, b = blockIdx.x / (Tq * H);
+  const uint16_t* qrow = qp + ((size_t)b * Tq + t) * ldq + h * dh;
+  for (int d = lane; d < dh; d += 64) qs[d] = T::to_f32(qrow[d]) * scale;  // q * dh^-1/2 first, as torch MHA does
+  __syncthreads();
+  float m = -INFINITY;
+  for (int key = lane; key < Tk; key += 64) {
+    float s = -INFINITY;
+    if (mask == nullptr || mask[(size_t)b * Tk + key]) s = dot16<T>(kp + ((size_t)b * Tk + key) * ldk + h * dh, qs, dh);
+    ps[key] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int key = lane; key < Tk; key += 64) {
+    const float p = __expf(ps[key] - m);  // all-masked row: (-inf) - (-inf) = NaN, as torch
+    ps[key] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = 1.0f / sum;
+  for (int d = lane; d < dh; d += 64) {
+    float acc = 0.f;
+    const uint16_t* vcol = vp + (size_t)b * Tk * ldv + h * dh + d;
+    for (int key = 0; key < Tk; ++key) acc += ps[key] * T::to_f32(vcol[(size_t)key * ldv]);
+    op[((size_t)b * Tq + t) * ldo + h * dh + d] = T::from_f32(acc * inv);
+  }
+  if (lse != nullptr && lane == 0) lse[((size_t)b * H + h) * Tq + t] = m + __logf(sum);
+}
+
+// dq pass: one wave per (b, h, query).  Also writes delta[b,h,t] = sum_d dO*O.
+template <typename T>
+__global__ void __launch_bounds__(64) attn_generic_bwd_q(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                         const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
+                                                         const uint16_t* __restrict__ op, const uint16_t* __restrict__ dop,
+                                                         const float* __restrict__ lse, uint16_t* __restrict__ dqp,
+                                                         float* __restrict__ delta, int H, int Tq, int Tk, int dh, int ldq,
+                                                         int ldk, int ldv, int ldo, int lddq, float scale) {
+  __shared__ float qs[ATT_MAX_DH];
+  __shared__ float dos[ATT_MAX_DH];
+  __shared__ float ds[ATT_MAX_TK];
+  const int lane = threadIdx.x;
+  const int t = blockIdx.x % Tq, h = (blockIdx.x / Tq) % H, b = blockIdx.x / (Tq * H);
+  const size_t qi = ((size_t)b * Tq + t);
+  float dl = 0.f;
+  for (int d = lane; d < dh; d += 64) {
+    qs[d] = T::to_f32(qp[qi * ldq + h * dh + d]) * scale;
+    const float g = T::to_f32(dop[qi * ldo + h * dh + d]);
+    dos[d] = g;
+    dl += g * T::to_f32(op[qi * ldo + h * dh + d]);
+  }
+  dl = wave_sum(dl);
+  __syncthreads();
+  const float l = lse[((size_t)b * H + h) * Tq + t];
+  if (lane == 0) delta[((size_t)b * H + h) * Tq + t] = dl;
+  for (int key = lane; key < Tk; key += 64) {
+    float dsv = 0.f;
+    if (mask == nullptr || mask[(size_t)b * Tk + key]) {
+      const size_t ki = (size_t)b * Tk + key;
+      const float p = __expf(dot16<T>(kp + ki * ldk + h * dh, qs, dh) - l);
+      const float dp = dot16<T>(vp + ki * ldv + h * dh, dos, dh);
+      dsv = p * (dp - dl);
+    }
+    ds[key] = dsv;
+  }
+  __syncthreads();
+  for (int d = lane; d < dh; d += 64) {
+    float acc = 0.f;
+    const uint16_t* kcol = kp + (size_t)b * Tk * ldk + h * dh + d;
+    for (int key = 0; key < Tk; ++key) acc += ds[key] * T::to_f32(kcol[(size_t)key * ldk]);
+    dqp[qi * lddq + h * dh + d] = T::from_f32(acc * scale);
+  }
+}
+
+// dk/dv pass: one wave per (b, h, key); loops over the queries.
+template <typename T>
+__global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                          const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
+                                                          const uint16_t* __restrict__ dop, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, uint16_t* __restrict__ dkp,
+                                                          uint16_t* __restrict__ dvp, int H, int Tq, int Tk, int dh, int ldq,
+                                                          int ldk, int ldv, int ldo, int lddk, int lddv, float scale) {
+  __shared__ float ks[ATT_MAX_DH];
+  __shared__ float vs[ATT_MAX_DH];
+  __shared__ float pbuf[ATT_MAX_TK];   // p[t]  for this key
+  __shared__ float dsbuf[ATT_MAX_TK];  // dS[t] for this key
+  const int lane = threadIdx.x;
+  const int key = blockIdx.x % Tk, h = (blockIdx.x / Tk) % H, b = blockIdx.x / (Tk * H);
+  const size_t ki = (size_t)b * Tk + key;
+  const bool live = (mask == nullptr) || mask[ki];
+  for (int d = lane; d < dh; d += 64) {
+    ks[d] = T::to_f32(kp[ki * ldk + h * dh + d]);
+    vs[d] = T::to_f32(vp[ki * ldv + h * dh + d]);
+  }
+  __syncthreads();
+  for (int t = lane; t < Tq; t += 64) {
+    float p = 0.f, dsv = 0.f;
+    if (live) {
+      const size_t qi = (size_t)b * Tq + t;
+      const size_t si = ((size_t)b * H + h) * Tq + t;
+      p = __expf(dot16<T>(qp + qi * ldq + h * dh, ks, dh) * scale - lse[si]);
+      const float dp = dot16<T>(dop + qi * ldo + h * dh, vs, dh);
+      dsv = p * (dp - delta[si]);
+    }
+    pbuf[t] = p;
+    dsbuf[t] = dsv;
+  }
+  __syncthreads();
+  for (int d = lane; d < dh; d += 64) {
+    float ak = 0.f, av = 0.f;
+    for (int t = 0; t < Tq; ++t) {
+      const size_t qi = (size_t)b * Tq + t;
+      ak += dsbuf[t] * T::to_f32(qp[qi * ldq + h * dh + d]);
+      av += pbuf[t] * T::to_f32(dop[qi * ldo + h * dh + d]);
+    }
+    dkp[ki * lddk + h * dh + d] = T::from_f32(ak * scale);
+    dvp[ki * lddv + h * dh + d] = T::from_f32(av);
+  }
+}
+
+static int check_generic(int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return VMC_E_ARG;
+  if (dh <= 0 || dh > ATT_MAX_DH || (dh % 8) || Tk > ATT_MAX_TK || Tq > ATT_MAX_TK) return VMC_E_SHAPE;
+  if ((ldq % 8) || (ldk % 8) || (ldv % 8) || (ldo % 8)) return VMC_E_ALIGN;
+  return 0;
+}
+
+extern "C" int vmc_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* out,
+                                 float* lse, int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
+                                 int dtype16, void* stream) {
+  if (!q || !k || !v || !out) return VMC_E_ARG;
+  int rc = check_generic(B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo);
+  if (rc) return rc;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return VMC_E_ALIGN;
+  const float scale = 1.0f / sqrtf((float)dh);
+  dim3 grid(B * H * Tq);
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(attn_generic_fwd<BF16>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(attn_generic_fwd<F16>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t vmc_attention_bwd_workspace_bytes(int B, int H, int Tq) { return (size_t)B * H * Tq * sizeof(float); }
+
+extern "C" int vmc_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, const void* out,
+                                 const void* dout, const float* lse, void* dq, void* dk, void* dv, int B, int H, int Tq,
+                                 int Tk, int dh, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                                 void* workspace, size_t workspace_bytes, int dtype16, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return VMC_E_ARG;
+  int rc = check_generic(B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo);
+  if (rc) return rc;
+  if (workspace_bytes < vmc_attention_bwd_workspace_bytes(B, H, Tq)) return VMC_E_ARG;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) return VMC_E_ALIGN;
+  const float scale = 1.0f / sqrtf((float)dh);
+  float* delta = (float*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+#define VMC_LAUNCH_BWD(TT)                                                                                                   \
+  hipLaunchKernelGGL(attn_generic_bwd_q<TT>, dim3(B * H * Tq), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,       \
+                     (const uint16_t*)v, key_mask, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dq, delta, H, \
+                     Tq, Tk, dh, ldq, ldk, ldv, ldo, lddq, scale);                                                            \
+  hipLaunchKernelGGL(attn_generic_bwd_kv<TT>, dim3(B * H * Tk), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,      \
+                     (const uint16_t*)v, key_mask, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, H, Tq, Tk, \
+                     dh, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+  if (dtype16 == VMC_BF16) {
+    VMC_LAUNCH_BWD(BF16)
+  } else if (dtype16 == VMC_F16) {
+    VMC_LAUNCH_BWD(F16)
+  } else {
+    return VMC_E_DTYPE;
+  }
+#undef VMC_LAUNCH_BWD
+  VMC_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,104 @@
+// Shared device helpers for libvmc (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vmc.h"
+#include "tile_index.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define VMC_LDS __attribute__((address_space(3)))
+#define VMC_GLOBAL __attribute__((address_space(1)))
+
+#define VMC_CHECK_LAUNCH()                          \
+  do {                                              \
+    hipError_t e_ = hipGetLastError();              \
+    if (e_ != hipSuccess) return (int)e_;           \
+  } while (0)
+
+// ---- 16-bit element traits ---------------------------------------------------------------------
+struct BF16 {
+  static constexpr int id = VMC_BF16;
+  __device__ static inline float to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+  __device__ static inline uint16_t from_f32(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, b);
+  }
+  __device__ static inline f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct F16 {
+  static constexpr int id = VMC_F16;
+  __device__ static inline float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  __device__ static inline uint16_t from_f32(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  __device__ static inline f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ inline uint32_t pack2(float lo, float hi) {
+  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+}
+template <typename T>
+__device__ inline void unpack2(uint32_t w, float& lo, float& hi) {
+  lo = T::to_f32((uint16_t)(w & 0xFFFFu));
+  hi = T::to_f32((uint16_t)(w >> 16));
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int ACT>
+__device__ inline float apply_act(float x) {
+  if (ACT == VMC_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if (ACT == VMC_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  if (ACT == VMC_ACT_RELU) return fmaxf(x, 0.0f);
+  return x;
+}
+__device__ inline float apply_act_rt(float x, int act) {
+  switch (act) {
+    case VMC_ACT_QUICKGELU: return apply_act<VMC_ACT_QUICKGELU>(x);
+    case VMC_ACT_GELU_ERF: return apply_act<VMC_ACT_GELU_ERF>(x);
+    case VMC_ACT_RELU: return apply_act<VMC_ACT_RELU>(x);
+    default: return x;
+  }
+}
+__device__ inline float act_grad_rt(float x, int act) {
+  switch (act) {
+    case VMC_ACT_QUICKGELU: {
+      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    case VMC_ACT_GELU_ERF: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case VMC_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+
+static inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)max_blocks) g = max_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}

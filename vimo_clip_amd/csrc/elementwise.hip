@@ -1,0 +1,436 @@
+// HBM-bound helper kernels: frame preprocess + patch extraction, casts, transposes, pooling (gfx950).
+#include "common.h"
+
+extern "C" int vmc_abi_version(void) { return 1; }
+
+extern "C" const char* vmc_error_string(int code) {
+  switch (code) {
+    case 0: return "success";
+    case VMC_E_ARG: return "vmc: bad argument (null pointer, non-positive size or too-small workspace)";
+    case VMC_E_ALIGN: return "vmc: pointer or stride violates the documented alignment";
+    case VMC_E_SHAPE: return "vmc: unsupported shape";
+    case VMC_E_DTYPE: return "vmc: unsupported dtype combination";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "vmc: unknown error";
+  }
+}
+
+// ---- K0: u8 NCHW frames -> normalised 16-bit patch matrix --------------------------------------
+// One thread per 4 consecutive pixels of one (frame, channel, row): coalesced 4-byte reads; the four
+// results land in (at most two) patch rows.
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ patches,
+                                                         int F, int R, int p, int kpad, int wrap) {
+  const int g = R / p;
+  const int quads_per_row = R >> 2;
+  const size_t total = (size_t)F * 3 * R * quads_per_row;
+  const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+  const float istd[3] = {1.0f / 0.26862954f, 1.0f / 0.26130258f, 1.0f / 0.27577711f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xq = (int)(i % quads_per_row);
+    size_t t = i / quads_per_row;
+    const int y = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % 3);
+    const int f = (int)(t / 3);
+    const uint32_t px = *(const uint32_t*)(frames + i * 4);
+    const int py = y / p, dy = y % p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = xq * 4 + j;
+      uint32_t v = (px >> (8 * j)) & 0xFFu;
+      if (wrap) v = (256u - v) & 0xFFu;
+      // same operation order as ToTensor (/255) then Normalize ((x - mean) / std)
+      const float val = ((float)v / 255.0f - mean[c]) * istd[c];
+      const int pxi = x / p, dx = x % p;
+      const size_t prow = ((size_t)f * g + py) * g + pxi;
+      patches[prow * kpad + (c * p + dy) * p + dx] = T::from_f32(val);
+    }
+  }
+}
+
+__global__ void zero_pad_cols_kernel(uint16_t* __restrict__ patches, size_t rows, int k, int kpad) {
+  const int padw = kpad - k;
+  const size_t total = rows * padw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    patches[(i / padw) * kpad + k + (i % padw)] = 0;
+}
+
+extern "C" int vmc_preprocess_patches_u8(const uint8_t* frames, void* patches, int F, int R, int p, int kpad, int wrap_quirk,
+                                         int dtype16, void* stream) {
+  if (!frames || !patches || F <= 0 || R <= 0 || p <= 0) return VMC_E_ARG;
+  if (R % p || R % 4 || kpad < 3 * p * p || kpad % 8) return VMC_E_SHAPE;
+  if ((uintptr_t)frames & 3) return VMC_E_ALIGN;
+  const size_t total = (size_t)F * 3 * R * (R / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const int k = 3 * p * p;
+  if (kpad > k) {
+    const size_t rows = (size_t)F * (R / p) * (R / p);
+    hipLaunchKernelGGL(zero_pad_cols_kernel, dim3(grid_for(rows * (kpad - k), 256)), dim3(256), 0, s, (uint16_t*)patches, rows, k, kpad);
+    VMC_CHECK_LAUNCH();
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(preprocess_kernel<BF16>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, (uint16_t*)patches, F, R, p, kpad, wrap_quirk);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(preprocess_kernel<F16>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, (uint16_t*)patches, F, R, p, kpad, wrap_quirk);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// Same patch extraction for frames that are already normalised floats (HF `pixel_values`, the
+// argument of CLIPModel.get_image_features at extract_embeddings.py:94).
+template <typename T>
+__global__ void __launch_bounds__(256) patches_f32_kernel(const float* __restrict__ pix, uint16_t* __restrict__ patches, int F, int R,
+                                                          int p, int kpad) {
+  const int g = R / p;
+  const int quads_per_row = R >> 2;
+  const size_t total = (size_t)F * 3 * R * quads_per_row;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xq = (int)(i % quads_per_row);
+    size_t t = i / quads_per_row;
+    const int y = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % 3);
+    const int f = (int)(t / 3);
+    const float4 px = *(const float4*)(pix + i * 4);
+    const float v[4] = {px.x, px.y, px.z, px.w};
+    const int py = y / p, dy = y % p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = xq * 4 + j;
+      const int pxi = x / p, dx = x % p;
+      const size_t prow = ((size_t)f * g + py) * g + pxi;
+      patches[prow * kpad + (c * p + dy) * p + dx] = T::from_f32(v[j]);
+    }
+  }
+}
+
+extern "C" int vmc_patches_f32(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16, void* stream) {
+  if (!pixel_values || !patches || F <= 0 || R <= 0 || p <= 0) return VMC_E_ARG;
+  if (R % p || R % 4 || kpad < 3 * p * p || kpad % 8) return VMC_E_SHAPE;
+  if ((uintptr_t)pixel_values & 15) return VMC_E_ALIGN;
+  const size_t total = (size_t)F * 3 * R * (R / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const int k = 3 * p * p;
+  if (kpad > k) {
+    const size_t rows = (size_t)F * (R / p) * (R / p);
+    hipLaunchKernelGGL(zero_pad_cols_kernel, dim3(grid_for(rows * (kpad - k), 256)), dim3(256), 0, s, (uint16_t*)patches, rows, k, kpad);
+    VMC_CHECK_LAUNCH();
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(patches_f32_kernel<BF16>, dim3(grid_for(total, 256)), dim3(256), 0, s, pixel_values, (uint16_t*)patches, F, R, p, kpad);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(patches_f32_kernel<F16>, dim3(grid_for(total, 256)), dim3(256), 0, s, pixel_values, (uint16_t*)patches, F, R, p, kpad);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- 16-bit transpose through a padded LDS tile --------------------------------------------------
+__global__ void __launch_bounds__(256) transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int rows,
+                                                          int cols, size_t ld_in, size_t ld_out) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+extern "C" int vmc_transpose16(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || ld_in < cols || ld_out < rows) return VMC_E_ARG;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)out, rows, cols,
+                     (size_t)ld_in, (size_t)ld_out);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- f32 weight -> 16-bit (+ transposed copy) ----------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) cast_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ w16,
+                                                          uint16_t* __restrict__ w16t, int rows, int cols, size_t ld_out,
+                                                          size_t ld_out_t) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    uint16_t v = 0;
+    if (r < rows && c < cols) {
+      v = T::from_f32(w[(size_t)r * cols + c]);
+      if (w16) w16[(size_t)r * ld_out + c] = v;
+    }
+    tile[i][tx] = v;
+  }
+  if (!w16t) return;
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) w16t[(size_t)c * ld_out_t + r] = tile[tx][i];
+  }
+}
+
+extern "C" int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows, int cols, int ld_out, int ld_out_t, int dtype16,
+                               void* stream) {
+  if (!w || (!w16 && !w16_t) || rows <= 0 || cols <= 0) return VMC_E_ARG;
+  if ((w16 && ld_out < cols) || (w16_t && ld_out_t < rows)) return VMC_E_ARG;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(cast_weight_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w16, (uint16_t*)w16_t, rows,
+                       cols, (size_t)ld_out, (size_t)ld_out_t);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(cast_weight_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)w16, (uint16_t*)w16_t, rows,
+                       cols, (size_t)ld_out, (size_t)ld_out_t);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- column sums (bias gradients): partials per row-slab, then a reduce ---------------------------
+#define COLSUM_SLABS 256
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const void* __restrict__ in, float* __restrict__ partial, int M, int N,
+                                                             size_t ld, int in_f32) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float a = 0.f;
+  if (in_f32)
+    for (int r = r0; r < r1; ++r) a += ((const float*)in)[(size_t)r * ld + col];
+  else
+    for (int r = r0; r < r1; ++r) a += T::to_f32(((const uint16_t*)in)[(size_t)r * ld + col]);
+  partial[(size_t)blockIdx.y * N + col] = a;
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float a = 0.f;
+  for (int s = 0; s < slabs; ++s) a += partial[(size_t)s * N + col];
+  out[col] = a;
+}
+static int colsum_slabs(int M) { return M < COLSUM_SLABS * 4 ? (M + 3) / 4 : COLSUM_SLABS; }
+extern "C" size_t vmc_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_slabs(M) * N * sizeof(float); }
+extern "C" int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!in || !out || !workspace || M <= 0 || N <= 0 || ld_in < N) return VMC_E_ARG;
+  if (workspace_bytes < vmc_colsum_workspace_bytes(M, N)) return VMC_E_ARG;
+  const int slabs = colsum_slabs(M);
+  dim3 grid((N + 255) / 256, slabs);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == VMC_F16)
+    hipLaunchKernelGGL(colsum_partial_kernel<F16>, grid, dim3(256), 0, s, in, (float*)workspace, M, N, (size_t)ld_in, 0);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<BF16>, grid, dim3(256), 0, s, in, (float*)workspace, M, N, (size_t)ld_in, in_dtype == VMC_F32);
+  VMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, slabs, N);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- class-token rows ----------------------------------------------------------------------------
+template <typename T>
+__global__ void set_class_rows_kernel(void* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b, int F, int D,
+                                      size_t row_stride, int x_f32) {
+  const size_t total = (size_t)F * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const size_t f = i / D;
+    const float v = a[d] + b[d];
+    if (x_f32) ((float*)x)[f * row_stride + d] = v;
+    else ((uint16_t*)x)[f * row_stride + d] = T::from_f32(v);
+  }
+}
+extern "C" int vmc_set_class_rows(void* x, const float* a, const float* b, int F, int D, size_t row_stride, int x_dtype, int dtype16,
+                                  void* stream) {
+  if (!x || !a || !b || F <= 0 || D <= 0) return VMC_E_ARG;
+  const int grid = grid_for((size_t)F * D, 256);
+  if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(set_class_rows_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, b, F, D, row_stride, x_dtype == VMC_F32);
+  else
+    hipLaunchKernelGGL(set_class_rows_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, b, F, D, row_stride, x_dtype == VMC_F32);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- activations on flat 16-bit arrays (training path) ---------------------------------------------
+template <typename T>
+__global__ void act_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n, int act) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * blockDim.x * 8) {
+    if (i + 8 <= n) {
+      const uint4 w = *(const uint4*)(x + i);
+      const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a, b;
+        unpack2<T>(in[j], a, b);
+        o[j] = pack2<T>(apply_act_rt(a, act), apply_act_rt(b, act));
+      }
+      *(uint4*)(y + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (size_t k = i; k < n; ++k) y[k] = T::from_f32(apply_act_rt(T::to_f32(x[k]), act));
+    }
+  }
+}
+template <typename T>
+__global__ void act_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, size_t n,
+                               int act) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * blockDim.x * 8) {
+    if (i + 8 <= n) {
+      const uint4 w = *(const uint4*)(x + i);
+      const uint4 g = *(const uint4*)(dy + i);
+      const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+      const uint32_t gi[4] = {g.x, g.y, g.z, g.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a, b, ga, gb;
+        unpack2<T>(in[j], a, b);
+        unpack2<T>(gi[j], ga, gb);
+        o[j] = pack2<T>(ga * act_grad_rt(a, act), gb * act_grad_rt(b, act));
+      }
+      *(uint4*)(dx + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      for (size_t k = i; k < n; ++k) dx[k] = T::from_f32(T::to_f32(dy[k]) * act_grad_rt(T::to_f32(x[k]), act));
+    }
+  }
+}
+extern "C" int vmc_act_fwd(const void* x, void* y, size_t n, int act, int dtype16, void* stream) {
+  if (!x || !y || n == 0) return VMC_E_ARG;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return VMC_E_ALIGN;
+  const int grid = grid_for((n + 7) / 8, 256);
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(act_fwd_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, act);
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(act_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, act);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int vmc_act_bwd(const void* x, const void* dy, void* dx, size_t n, int act, int dtype16, void* stream) {
+  if (!x || !dy || !dx || n == 0) return VMC_E_ARG;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return VMC_E_ALIGN;
+  const int grid = grid_for((n + 7) / 8, 256);
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(act_bwd_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, n, act);
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(act_bwd_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, n, act);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- mean over T ----------------------------------------------------------------------------------
+template <typename T>
+__global__ void mean_pool_kernel(const void* __restrict__ x, uint16_t* __restrict__ o16, float* __restrict__ o32, int B, int Tn, int D,
+                                 int x_f32) {
+  const size_t total = (size_t)B * D;
+  const float inv = 1.0f / (float)Tn;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const size_t b = i / D;
+    float a = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+      const size_t idx = (b * Tn + t) * D + d;
+      a += x_f32 ? ((const float*)x)[idx] : T::to_f32(((const uint16_t*)x)[idx]);
+    }
+    a *= inv;
+    if (o16) o16[i] = T::from_f32(a);
+    if (o32) o32[i] = a;
+  }
+}
+extern "C" int vmc_mean_pool(const void* x, void* out16, float* out32, int B, int Tn, int D, int x_dtype, int dtype16, void* stream) {
+  if (!x || (!out16 && !out32) || B <= 0 || Tn <= 0 || D <= 0) return VMC_E_ARG;
+  const int grid = grid_for((size_t)B * D, 256);
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(mean_pool_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out16, out32, B, Tn, D, x_dtype == VMC_F32);
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(mean_pool_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)out16, out32, B, Tn, D, x_dtype == VMC_F32);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- sinusoidal positional encoding (TFAM/models/AMO_CLIP.py:88-97), added in place ---------------
+__global__ void add_pe_kernel(float* __restrict__ x, int B, int Tn, int D) {
+  const size_t total = (size_t)B * Tn * D;
+  const float c = -9.210340371976184f / (float)D;  // -ln(10000)/D
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % Tn);
+    const float div = expf((float)(d & ~1) * c);
+    const float ang = (float)t * div;
+    x[i] += (d & 1) ? cosf(ang) : sinf(ang);
+  }
+}
+extern "C" int vmc_add_sinusoidal_pe(float* x, int B, int Tn, int D, void* stream) {
+  if (!x || B <= 0 || Tn <= 0 || D <= 0 || (D & 1)) return VMC_E_ARG;
+  hipLaunchKernelGGL(add_pe_kernel, dim3(grid_for((size_t)B * Tn * D, 256)), dim3(256), 0, (hipStream_t)stream, x, B, Tn, D);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- y = alpha*a + beta*b, f32 ------------------------------------------------------------------------
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n, float alpha,
+                             float beta) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = alpha * a[i] + beta * b[i];
+}
+extern "C" int vmc_axpby_f32(const float* a, const float* b, float* y, size_t n, float alpha, float beta, void* stream) {
+  if (!a || !b || !y || n == 0) return VMC_E_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, alpha, beta);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- flat casts ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_to16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      const float4 v = *(const float4*)(x + i);
+      *(uint2*)(y + i) = make_uint2(pack2<T>(v.x, v.y), pack2<T>(v.z, v.w));
+    } else {
+      for (size_t k = i; k < n; ++k) y[k] = T::from_f32(x[k]);
+    }
+  }
+}
+template <typename T>
+__global__ void cast_to32_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      const uint2 w = *(const uint2*)(x + i);
+      float4 v;
+      unpack2<T>(w.x, v.x, v.y);
+      unpack2<T>(w.y, v.z, v.w);
+      *(float4*)(y + i) = v;
+    } else {
+      for (size_t k = i; k < n; ++k) y[k] = T::to_f32(x[k]);
+    }
+  }
+}
+extern "C" int vmc_cast_f32_to_16(const float* x, void* y, size_t n, int dtype16, void* stream) {
+  if (!x || !y || n == 0) return VMC_E_ARG;
+  if (((uintptr_t)x & 15) | ((uintptr_t)y & 7)) return VMC_E_ALIGN;
+  const int grid = grid_for((n + 3) / 4, 256);
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(cast_to16_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n);
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(cast_to16_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, n);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int vmc_cast_16_to_f32(const void* x, float* y, size_t n, int dtype16, void* stream) {
+  if (!x || !y || n == 0) return VMC_E_ARG;
+  if (((uintptr_t)y & 15) | ((uintptr_t)x & 7)) return VMC_E_ALIGN;
+  const int grid = grid_for((n + 3) / 4, 256);
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(cast_to32_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, y, n);
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(cast_to32_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, y, n);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,268 @@
+// vmc_linear: C = epilogue(A @ W^T), 16-bit operands, fp32 MFMA accumulation (gfx950).
+//
+// Structure (cdna_hip_programming.md §5): block tile (16*MT*WM) x (64*WN), BK = 64, two LDS stages
+// filled by global_load_lds_dwordx4 (LDS image lane-linear, XOR swizzle applied on the per-lane SOURCE
+// address and on the ds_read_b128 address), one vmcnt(0)+barrier per K tile with the next tile's DMA
+// in flight under the MFMAs.  Operands are passed to v_mfma_f32_16x16x32 as (W, X) so each lane owns
+// 16 consecutive output columns of one row -> bias/residual/stores are 16-byte vectors.
+#include "common.h"
+
+struct GemmArgs {
+  const char* A;
+  const char* W;
+  const float* bias;
+  const char* res;
+  char* C;
+  int M, N, K;
+  int lda, ldw, ldc, ldres;
+  float alpha;
+  int out_f32, res_f32;
+  int out_row_group, res_row_mod;
+  int tiles_m, tiles_n;
+};
+
+template <int MT, int WM, int WN>
+struct GemmCfg {
+  static constexpr int BM = 16 * MT * WM;
+  static constexpr int BN = 64 * WN;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int B_BYTES = BN * 128;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_ITERS = BM * 8 / NT;
+  static constexpr int B_ITERS = BN * 8 / NT;
+  static constexpr int LDS = 2 * STAGE;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging must divide evenly");
+};
+
+// One K tile: issue the LDS-DMA of the NEXT tile into `wr`, then MFMA over the tile in `rd`.
+// `rd` / `wr` are __restrict__ so the compiler's waitcnt pass knows the ds_reads cannot alias the
+// in-flight global_load_lds and does not drain vmcnt in front of them (checked in the .s).
+template <typename T, int MT, int WM, int WN>
+__device__ __forceinline__ void gemm_step(const char* __restrict__ rd, char* __restrict__ wr, bool do_stage, size_t koff,
+                                          const char* const (&a_src)[GemmCfg<MT, WM, WN>::A_ITERS],
+                                          const char* const (&b_src)[GemmCfg<MT, WM, WN>::B_ITERS], int wave_lds,
+                                          const int (&xoff)[2], const int (&woff)[2][4], f32x4 (&acc)[MT][4]) {
+  using Cfg = GemmCfg<MT, WM, WN>;
+  if (do_stage) {
+#pragma unroll
+    for (int i = 0; i < Cfg::A_ITERS; ++i)
+      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(a_src[i] + koff),
+                                       (VMC_LDS void*)(wr + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_ITERS; ++i)
+      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(b_src[i] + koff),
+                                       (VMC_LDS void*)(wr + Cfg::A_BYTES + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+  }
+  // keep the DMA issue ahead of this tile's ds_reads/MFMAs (hipcc otherwise sinks it to the end of the
+  // step, right in front of the vmcnt(0) that waits for it)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    uint4 wf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const uint4*)(rd + woff[kk][nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      uint4 xf = *(const uint4*)(rd + xoff[kk] + mt * 2048);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = T::mfma16(wf[nt], xf, acc[mt][nt]);
+    }
+  }
+}
+
+template <typename T, int ACT, int MT, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
+  using Cfg = GemmCfg<MT, WM, WN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 15, q = lane >> 4;
+
+  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+
+  // ---- per-thread staging sources (row pointers are loop-invariant, only k advances) ----
+  const char* a_src[Cfg::A_ITERS];
+  const char* b_src[Cfg::B_ITERS];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_ITERS; ++i) {
+    int row, ch;
+    stage_src_x(i * Cfg::NT + tid, row, ch);
+    int grow = min(m0 + row, g.M - 1);
+    a_src[i] = g.A + ((size_t)grow * g.lda + ch * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_ITERS; ++i) {
+    int row, ch;
+    stage_src_w(i * Cfg::NT + tid, row, ch);
+    int grow = min(n0 + row, g.N - 1);
+    b_src[i] = g.W + ((size_t)grow * g.ldw + ch * 8) * 2;
+  }
+  const int wave_lds = wave * 1024;  // this wave's 64 x 16 B slice inside each NT*16-byte staging pass
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a stage
+  int xoff[2], woff[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    xoff[kk] = lds_off_x(wm * 16 * MT + r, 4 * kk + q);  // + mt * 2048
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) woff[kk][nt] = Cfg::A_BYTES + lds_off_w(wn * 64 + gemm_w_row(r, nt), 4 * kk + q);
+  }
+
+  const int nkt = g.K / 64;
+  char* const buf0 = smem;
+  char* const buf1 = smem + Cfg::STAGE;
+  // prologue: tile 0 -> buf0
+#pragma unroll
+  for (int i = 0; i < Cfg::A_ITERS; ++i)
+    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(a_src[i]), (VMC_LDS void*)(buf0 + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < Cfg::B_ITERS; ++i)
+    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(b_src[i]),
+                                     (VMC_LDS void*)(buf0 + Cfg::A_BYTES + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_step<T, MT, WM, WN>(buf0, buf1, true, (size_t)(kt + 1) * 128, a_src, b_src, wave_lds, xoff, woff, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_step<T, MT, WM, WN>(buf1, buf0, kt + 2 < nkt, (size_t)(kt + 2) * 128, a_src, b_src, wave_lds, xoff, woff, acc);
+  }
+  if (kt < nkt) {  // odd tile count: last tile sits in buf0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_step<T, MT, WM, WN>(buf0, buf1, false, 0, a_src, b_src, wave_lds, xoff, woff, acc);
+  }
+
+  // ---- epilogue: lane owns C[row][col0 .. col0+15] for each mt ----
+  const int col0 = n0 + wn * 64 + 16 * q;
+  const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.res == nullptr || (g.ldres & 7) == 0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = m0 + wm * 16 * MT + 16 * mt + r;
+    if (row >= g.M) continue;
+    const int orow = g.out_row_group ? row + row / g.out_row_group + 1 : row;
+    const int rrow = g.res_row_mod ? row % g.res_row_mod : orow;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const int col = col0 + 4 * c4;
+      if (col >= g.N) continue;
+      float* x = &v[4 * c4];
+      if (g.bias) {
+        const float4 b = *(const float4*)(g.bias + col);
+        x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = g.alpha * apply_act<ACT>(x[j]);
+      if (g.res) {
+        if (g.res_f32) {
+          const float4 rr = *(const float4*)((const float*)g.res + (size_t)rrow * g.ldres + col);
+          x[0] += rr.x; x[1] += rr.y; x[2] += rr.z; x[3] += rr.w;
+        } else {
+          const uint2 rr = *(const uint2*)((const uint16_t*)g.res + (size_t)rrow * g.ldres + col);
+          float a, b;
+          unpack2<T>(rr.x, a, b); x[0] += a; x[1] += b;
+          unpack2<T>(rr.y, a, b); x[2] += a; x[3] += b;
+        }
+      }
+    }
+    if (g.out_f32) {
+      float* dst = (float*)g.C + (size_t)orow * g.ldc + col0;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+        if (col0 + 4 * c4 < g.N) *(float4*)(dst + 4 * c4) = make_float4(v[4 * c4], v[4 * c4 + 1], v[4 * c4 + 2], v[4 * c4 + 3]);
+    } else {
+      uint16_t* dst = (uint16_t*)g.C + (size_t)orow * g.ldc + col0;
+      if (vec8) {
+#pragma unroll
+        for (int c8 = 0; c8 < 2; ++c8)
+          if (col0 + 8 * c8 < g.N)
+            *(uint4*)(dst + 8 * c8) = make_uint4(pack2<T>(v[8 * c8], v[8 * c8 + 1]), pack2<T>(v[8 * c8 + 2], v[8 * c8 + 3]),
+                                                 pack2<T>(v[8 * c8 + 4], v[8 * c8 + 5]), pack2<T>(v[8 * c8 + 6], v[8 * c8 + 7]));
+      } else {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+          if (col0 + 4 * c4 < g.N)
+            *(uint2*)(dst + 4 * c4) = make_uint2(pack2<T>(v[4 * c4], v[4 * c4 + 1]), pack2<T>(v[4 * c4 + 2], v[4 * c4 + 3]));
+      }
+    }
+  }
+}
+
+template <typename T, int ACT, int MT, int WM, int WN>
+static int launch_cfg(GemmArgs& g, hipStream_t stream) {
+  using Cfg = GemmCfg<MT, WM, WN>;
+  auto kern = gemm_kernel<T, ACT, MT, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+  g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(Cfg::NT), Cfg::LDS, stream, g);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int ACT>
+static int launch_shape(GemmArgs& g, hipStream_t stream) {
+  // Tile choice: the 256x256 tile needs >= ~1 tile per CU to pay; smaller problems take smaller tiles
+  // so the grid still covers the 256 CUs (TFAM/head GEMMs have M = B*16 or B rows).
+  const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+  const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if (t256 >= 192) return launch_cfg<T, ACT, 8, 2, 4>(g, stream);
+  if (t128 >= 128) return launch_cfg<T, ACT, 4, 2, 2>(g, stream);
+  return launch_cfg<T, ACT, 2, 2, 1>(g, stream);
+}
+
+template <typename T>
+static int launch_act(GemmArgs& g, int act, hipStream_t stream) {
+  switch (act) {
+    case VMC_ACT_NONE: return launch_shape<T, VMC_ACT_NONE>(g, stream);
+    case VMC_ACT_QUICKGELU: return launch_shape<T, VMC_ACT_QUICKGELU>(g, stream);
+    case VMC_ACT_GELU_ERF: return launch_shape<T, VMC_ACT_GELU_ERF>(g, stream);
+    case VMC_ACT_RELU: return launch_shape<T, VMC_ACT_RELU>(g, stream);
+  }
+  return VMC_E_ARG;
+}
+
+extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const void* res, void* C,
+                          int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                          int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                          int dtype16, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+  if (K % 64 != 0 || N % 4 != 0) return VMC_E_SHAPE;
+  if (lda % 8 || ldw % 8 || ldc % 4 || (res && (ldres % 4))) return VMC_E_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)res | (uintptr_t)bias) & 15) return VMC_E_ALIGN;
+  if (lda < K || ldw < K || ldc < N) return VMC_E_ARG;
+  if (out_dtype != VMC_F32 && out_dtype != dtype16) return VMC_E_DTYPE;
+  if (res && res_dtype != VMC_F32 && res_dtype != dtype16) return VMC_E_DTYPE;
+  GemmArgs g;
+  g.A = (const char*)A; g.W = (const char*)W; g.bias = bias; g.res = (const char*)res; g.C = (char*)C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldres = ldres;
+  g.alpha = alpha; g.out_f32 = (out_dtype == VMC_F32); g.res_f32 = (res_dtype == VMC_F32);
+  g.out_row_group = out_row_group; g.res_row_mod = res_row_mod;
+  g.tiles_m = g.tiles_n = 0;
+  if (dtype16 == VMC_BF16) return launch_act<BF16>(g, act, (hipStream_t)stream);
+  return launch_act<F16>(g, act, (hipStream_t)stream);
+}

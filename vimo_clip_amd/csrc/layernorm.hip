@@ -1,0 +1,209 @@
+// LayerNorm forward / backward, one wave per row, fp32 statistics (gfx950).  HBM-bound: 16-byte loads.
+#include "common.h"
+
+#define LN_MAX_CHUNKS 16  // D <= 16 * 256 = 4096
+
+template <typename T>
+__device__ inline float4 load4(const void* base, size_t idx, bool is_f32) {
+  if (is_f32) return *(const float4*)((const float*)base + idx);
+  const uint2 w = *(const uint2*)((const uint16_t*)base + idx);
+  float4 o;
+  unpack2<T>(w.x, o.x, o.y);
+  unpack2<T>(w.y, o.z, o.w);
+  return o;
+}
+template <typename T>
+__device__ inline void store4(void* base, size_t idx, bool is_f32, float4 v) {
+  if (is_f32)
+    *(float4*)((float*)base + idx) = v;
+  else
+    *(uint2*)((uint16_t*)base + idx) = make_uint2(pack2<T>(v.x, v.y), pack2<T>(v.z, v.w));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, uint16_t* __restrict__ y16,
+                                                     float* __restrict__ y32, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int rows, int D, size_t ldx, float eps,
+                                                     int x_f32) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const float invD = 1.0f / (float)D;
+  for (int row = wave_global; row < rows; row += nwaves) {
+    float4 v[LN_MAX_CHUNKS];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        v[c] = load4<T>(x, (size_t)row * ldx + col, x_f32);
+        s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+        ss += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float4 g = *(const float4*)(gamma + col);
+        const float4 b = *(const float4*)(beta + col);
+        float4 o;
+        o.x = (v[c].x - mean) * rstd * g.x + b.x;
+        o.y = (v[c].y - mean) * rstd * g.y + b.y;
+        o.z = (v[c].z - mean) * rstd * g.z + b.z;
+        o.w = (v[c].w - mean) * rstd * g.w + b.w;
+        if (y16) store4<T>(y16, (size_t)row * D + col, false, o);
+        if (y32) store4<T>(y32, (size_t)row * D + col, true, o);
+      }
+    }
+  }
+}
+
+extern "C" int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y16, float* y32, float* mean,
+                                 float* rstd, int rows, int D, int ldx, float eps, int x_dtype, int dtype16, void* stream) {
+  if (!x || !gamma || !beta || (!y16 && !y32) || rows <= 0 || D <= 0) return VMC_E_ARG;
+  if (D % 4 || D > LN_MAX_CHUNKS * 256) return VMC_E_SHAPE;
+  if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
+  if (x_dtype != VMC_F32 && x_dtype != dtype16) return VMC_E_DTYPE;
+  const int grid = grid_for((size_t)rows, 4, 256 * 8);
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(ln_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y16, y32,
+                       mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(ln_fwd_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y16, y32,
+                       mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+// dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));  dgamma = sum_rows g*xhat;  dbeta = sum_rows g.
+// Each wave accumulates its rows' dgamma/dbeta partials in registers, then one partial row per block
+// goes to the workspace [grid, 2, D]; a second kernel reduces the partials (deterministic, no atomics).
+#define LN_BWD_BLOCKS 512
+#define LN_BWD_MAX_CHUNKS 8  // D <= 2048 in the backward (register budget: 4 float4 arrays)
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, void* __restrict__ dx,
+                                                     float* __restrict__ partial, int rows, int D, size_t ldx, int dy_f32,
+                                                     int x_f32, int dx_f32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][2][D] floats
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+  const float invD = 1.0f / (float)D;
+  float4 dg[LN_BWD_MAX_CHUNKS], db[LN_BWD_MAX_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[LN_BWD_MAX_CHUNKS], xh[LN_BWD_MAX_CHUNKS];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float4 gy = load4<T>(dy, (size_t)row * D + col, dy_f32);
+        const float4 xv = load4<T>(x, (size_t)row * ldx + col, x_f32);
+        const float4 w = *(const float4*)(gamma + col);
+        xh[c] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        dg[c].x += gy.x * xh[c].x; dg[c].y += gy.y * xh[c].y; dg[c].z += gy.z * xh[c].z; dg[c].w += gy.w * xh[c].w;
+        db[c].x += gy.x; db[c].y += gy.y; db[c].z += gy.z; db[c].w += gy.w;
+        g[c] = make_float4(gy.x * w.x, gy.y * w.y, gy.z * w.z, gy.w * w.w);
+        s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
+        s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        float4 o;
+        o.x = rs * (g[c].x - s1 - xh[c].x * s2);
+        o.y = rs * (g[c].y - s1 - xh[c].y * s2);
+        o.z = rs * (g[c].z - s1 - xh[c].z * s2);
+        o.w = rs * (g[c].w - s1 - xh[c].w * s2);
+        store4<T>(dx, (size_t)row * D + col, dx_f32, o);
+      }
+    }
+  }
+  // block-level reduction of dgamma/dbeta partials
+  float* sm = (float*)smem;
+#pragma unroll
+  for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (col < D) {
+      *(float4*)(sm + (size_t)(wave * 2 + 0) * D + col) = dg[c];
+      *(float4*)(sm + (size_t)(wave * 2 + 1) * D + col) = db[c];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int which = i / D, col = i % D;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) a += sm[(size_t)(w * 2 + which) * D + col];
+    partial[((size_t)blockIdx.x * 2 + which) * D + col] = a;
+  }
+}
+
+__global__ void ln_bwd_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                              int nblocks, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * D) return;
+  const int which = i / D, col = i % D;
+  float a = 0.f;
+  for (int b = 0; b < nblocks; ++b) a += partial[((size_t)b * 2 + which) * D + col];
+  (which ? dbeta : dgamma)[col] = a;
+}
+
+static int ln_bwd_grid(int rows) { return grid_for((size_t)rows, 4, LN_BWD_BLOCKS); }
+
+extern "C" size_t vmc_layernorm_bwd_workspace_bytes(int rows, int D) {
+  return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
+}
+
+extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype, int x_dtype,
+                                 int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return VMC_E_ARG;
+  if (D % 4 || D > LN_BWD_MAX_CHUNKS * 256) return VMC_E_SHAPE;
+  if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
+  if (workspace_bytes < vmc_layernorm_bwd_workspace_bytes(rows, D)) return VMC_E_ARG;
+  const int grid = ln_bwd_grid(rows);
+  const size_t lds = (size_t)8 * D * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(ln_bwd_kernel<BF16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, (float*)workspace, rows,
+                       D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(ln_bwd_kernel<F16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, (float*)workspace, rows, D,
+                       (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 255) / 256), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}

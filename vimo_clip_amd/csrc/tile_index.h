@@ -1,0 +1,57 @@
+// Pure index arithmetic of the MFMA tiles (LDS images, swizzles, fragment -> element maps).
+// Shared by the kernels and by tests/host/test_tile_index.cpp, which emulates the lanes of a wave on
+// the CPU (LDS-DMA placement rule + the MFMA operand/accumulator lane maps) and checks every kernel's
+// index math against a plain matrix product before anything runs on a GPU.
+//
+// Hardware facts used (cdna_hip_programming.md §3, §5; MI355X_MICROARCH.md §LDS):
+//   v_mfma_f32_16x16x32_{bf16,f16}: lane l holds A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15],
+//   j = 0..7; accumulator reg j of lane l is D[row 4(l>>4)+j][col l&15].
+//   global_load_lds_dwordx4: lane i of a wave writes LDS bytes [base + 16 i, +16) (lane-linear image),
+//   the global source address is per lane -> swizzles are applied to the SOURCE and to the READ.
+//   ds_read_b128 is serviced in four 16-lane groups; bank = (addr/4) % 64.
+#pragma once
+
+#if defined(__HIPCC__)
+#define VMC_HD __host__ __device__ inline
+#else
+#define VMC_HD inline
+#endif
+
+// LDS tile image: rows of 64 16-bit elements = 128 B = 8 chunks of 16 B.  Physical chunk = logical
+// chunk XOR f(row); f chosen so that every ds_read_b128 lane group touches 16 distinct 16-B slots.
+// X-operand rows are read as 16 consecutive rows per instruction:
+VMC_HD int swz_x(int row) { return (row >> 1) & 7; }
+// W-operand rows are read as rows {16*(r>>2) + 4*nt + (r&3)} (r = lane&15) so that each lane ends up
+// with 16 consecutive output columns; distinct slots need row bits {1,4,5}:
+VMC_HD int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+VMC_HD int lds_off_x(int row, int chunk) { return row * 128 + ((chunk ^ swz_x(row)) << 4); }
+VMC_HD int lds_off_w(int row, int chunk) { return row * 128 + ((chunk ^ swz_w(row)) << 4); }
+
+// GEMM wave tile: (16*MT) rows x 64 cols.  Lane (r = lane&15, q = lane>>4):
+//   X fragment (mt, kk): tile row 16*mt + r, logical chunk 4*kk + q
+//   W fragment (nt, kk): tile row 16*(r>>2) + 4*nt + (r&3), logical chunk 4*kk + q
+//   acc[mt][nt][j] = C[row 16*mt + r][col 16*q + 4*nt + j]      (operands passed as mfma(W, X))
+VMC_HD int gemm_w_row(int r, int nt) { return 16 * (r >> 2) + 4 * nt + (r & 3); }
+VMC_HD int gemm_c_col(int q, int nt, int j) { return 16 * q + 4 * nt + j; }
+
+// Staging: 16-B chunk `idx` (LDS order) of an operand tile -> (row, logical chunk) to fetch.
+VMC_HD void stage_src_x(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_x(row); }
+VMC_HD void stage_src_w(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w(row); }
+
+// Bijective XCD-aware remap of a 1-D block id (blocks b and b+8 share an XCD; give each XCD a
+// contiguous range of tiles so neighbouring tiles share operand panels in that XCD's L2).
+VMC_HD int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+// ---- attention (ViT, head_dim 64) -------------------------------------------------------------
+// K tile image = X-style rows (key major).  V tile image: rows = keys, read by ds_read_b64_tr_b16 as
+// 4-key x 16-column blocks; swizzle keeps the 32 lanes of a half on 32 distinct 8-B bank pairs.
+VMC_HD int swz_v(int key) { return ((key >> 1) & 3) << 1; }
+VMC_HD int lds_off_v(int key, int chunk) { return key * 128 + ((chunk ^ swz_v(key)) << 4); }
+// S^T = K Q^T accumulators: tile nt, reg j of lane (r, q) is score[query r][key 16*nt + 4*q + j].
+// P operand of k-step s (32 keys): element j<4 -> key 32 s + 4 q + j ; j>=4 -> key 32 s + 16 + 4 q + (j-4)
+VMC_HD int attn_pv_key(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }

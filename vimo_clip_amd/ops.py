@@ -1,0 +1,178 @@
+"""Checked Python entry points over the libvmc C ABI (include/vmc.h).
+
+PyTorch is used for device memory and streams only: every function here enqueues HIP kernels on the
+current stream and returns tensors allocated by the caching allocator.  No function has a PyTorch
+compute fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, ACT_RELU, F32, check, dt, lib, ptr, stream  # noqa: F401
+
+
+def _kpad(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+def cast_weight(w: torch.Tensor, dtype16: torch.dtype, transposed: bool = False, pad_k: bool = False):
+    """fp32 [rows, cols] parameter -> 16-bit compute copy (optionally the transposed copy instead).
+    pad_k pads the K (= last) dimension of the copy with zeros up to a multiple of 64."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    if w2.dtype != torch.float32 or not w2.is_contiguous():
+        w2 = w2.float().contiguous()
+    rows, cols = w2.shape
+    if transposed:
+        ld = _kpad(rows) if pad_k else rows
+        out = (torch.zeros if ld != rows else torch.empty)((cols, ld), dtype=dtype16, device=w.device)
+        check(lib.vmc_cast_weight(ptr(w2), None, ptr(out), rows, cols, 0, ld, dt(dtype16), stream()), "cast_weight")
+    else:
+        ld = _kpad(cols) if pad_k else cols
+        out = (torch.zeros if ld != cols else torch.empty)((rows, ld), dtype=dtype16, device=w.device)
+        check(lib.vmc_cast_weight(ptr(w2), ptr(out), None, rows, cols, ld, 0, dt(dtype16), stream()), "cast_weight")
+    return out
+
+
+def cast16(x: torch.Tensor, dtype16: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype16:
+        return x
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype16, device=x.device)
+    check(lib.vmc_cast_f32_to_16(ptr(x), ptr(y), x.numel(), dt(dtype16), stream()), "cast_f32_to_16")
+    return y
+
+
+def cast32(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == torch.float32:
+        return x
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.vmc_cast_16_to_f32(ptr(x), ptr(y), x.numel(), dt(x), stream()), "cast_16_to_f32")
+    return y
+
+
+def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = ACT_NONE, alpha: float = 1.0,
+           out_dtype=None, out=None, out_row_group: int = 0, res_row_mod: int = 0, out_rows=None,
+           lda=None) -> torch.Tensor:
+    """C = alpha * act(A @ W^T + bias) + res   (vmc_linear).  a: [M,K] 16-bit (row stride lda), w16: [N,K]."""
+    M = a.shape[0]
+    K = w16.shape[1]
+    N = w16.shape[0]
+    lda = a.stride(0) if lda is None else lda
+    if a.stride(-1) != 1 or w16.stride(-1) != 1:
+        raise ValueError("linear: operands must be contiguous in K")
+    out_dtype = out_dtype or (out.dtype if out is not None else a.dtype)
+    if out is None:
+        out = torch.empty((out_rows or M, N), dtype=out_dtype, device=a.device)
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("linear: bias must be float32")
+    check(lib.vmc_linear(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), M, N, K, lda, w16.stride(0), out.stride(0),
+                         res.stride(0) if res is not None else 0, act, float(alpha), dt(out), dt(res) if res is not None else 0,
+                         out_row_group, res_row_mod, dt(a), stream()), "linear")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False, y32=None, rows=None, ldx=None,
+              eps: float = 1e-5, save_stats: bool = False):
+    """LayerNorm over the last dim of x viewed as [rows, D] with row stride ldx.  Returns (y16, y32, mean, rstd)."""
+    D = gamma.shape[0]
+    rows = x.numel() // D if rows is None else rows
+    ldx = D if ldx is None else ldx
+    y16 = torch.empty((rows, D), dtype=dtype16, device=x.device) if out16 else None
+    if out32 and y32 is None:
+        y32 = torch.empty((rows, D), dtype=torch.float32, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib.vmc_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean), ptr(rstd), rows, D, ldx,
+                                float(eps), dt(x), dt(dtype16), stream()), "layernorm_fwd")
+    return y16, y32, mean, rstd
+
+
+def attention_vit(qkv: torch.Tensor, F: int, N: int, H: int, want_lse: bool = False):
+    D = H * 64
+    out = torch.empty((F * N, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((F, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(lib.vmc_attention_vit_fwd(ptr(qkv), ptr(out), ptr(lse), F, N, H, dt(qkv), stream()), "attention_vit_fwd")
+    return out, lse
+
+
+def attention(q, k, v, key_mask_u8, B, H, Tq, Tk, dh, want_lse=False):
+    """Generic masked attention.  q/k/v are 2-D 16-bit views [B*T, ld] whose first H*dh columns are used."""
+    out = torch.empty((B * Tq, H * dh), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if want_lse else None
+    check(lib.vmc_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask_u8), ptr(out), ptr(lse), B, H, Tq, Tk, dh,
+                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), dt(q), stream()), "attention_fwd")
+    return out, lse
+
+
+def preprocess_patches_u8(frames_u8: torch.Tensor, patch: int, dtype16, wrap_quirk: bool) -> torch.Tensor:
+    F, C, R, R2 = frames_u8.shape
+    if C != 3 or R != R2 or frames_u8.dtype != torch.uint8:
+        raise ValueError("frames must be u8 [F,3,R,R]")
+    frames_u8 = frames_u8.contiguous()
+    g = R // patch
+    kpad = _kpad(3 * patch * patch)
+    out = torch.empty((F * g * g, kpad), dtype=dtype16, device=frames_u8.device)
+    check(lib.vmc_preprocess_patches_u8(ptr(frames_u8), ptr(out), F, R, patch, kpad, int(wrap_quirk), dt(dtype16), stream()),
+          "preprocess_patches_u8")
+    return out
+
+
+def patches_f32(pixel_values: torch.Tensor, patch: int, dtype16) -> torch.Tensor:
+    F, C, R, R2 = pixel_values.shape
+    if C != 3 or R != R2:
+        raise ValueError("pixel_values must be [F,3,R,R]")
+    pixel_values = pixel_values.float().contiguous()
+    g = R // patch
+    kpad = _kpad(3 * patch * patch)
+    out = torch.empty((F * g * g, kpad), dtype=dtype16, device=pixel_values.device)
+    check(lib.vmc_patches_f32(ptr(pixel_values), ptr(out), F, R, patch, kpad, dt(dtype16), stream()), "patches_f32")
+    return out
+
+
+def set_class_rows(x: torch.Tensor, a, b, F: int, D: int, row_stride: int, dtype16):
+    check(lib.vmc_set_class_rows(ptr(x), ptr(a), ptr(b), F, D, row_stride, dt(x), dt(dtype16), stream()), "set_class_rows")
+
+
+def mean_pool(x: torch.Tensor, B: int, T: int, D: int, dtype16, out16=True, out32=False):
+    o16 = torch.empty((B, D), dtype=dtype16, device=x.device) if out16 else None
+    o32 = torch.empty((B, D), dtype=torch.float32, device=x.device) if out32 else None
+    check(lib.vmc_mean_pool(ptr(x), ptr(o16), ptr(o32), B, T, D, dt(x), dt(dtype16), stream()), "mean_pool")
+    return o16, o32
+
+
+def add_sinusoidal_pe_(x: torch.Tensor):
+    B, T, D = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("add_sinusoidal_pe_: need contiguous float32 [B,T,D]")
+    check(lib.vmc_add_sinusoidal_pe(ptr(x), B, T, D, stream()), "add_sinusoidal_pe")
+    return x
+
+
+def transpose16(x: torch.Tensor) -> torch.Tensor:
+    rows, cols = x.shape
+    out = torch.empty((cols, rows), dtype=x.dtype, device=x.device)
+    check(lib.vmc_transpose16(ptr(x), ptr(out), rows, cols, x.stride(0), rows, stream()), "transpose16")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    nbytes = lib.vmc_colsum_workspace_bytes(M, N)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    check(lib.vmc_colsum(ptr(x), ptr(out), M, N, x.stride(0), dt(x), ptr(ws), nbytes, stream()), "colsum")
+    return out
+
+
+def act_fwd(x: torch.Tensor, act: int) -> torch.Tensor:
+    y = torch.empty_like(x)
+    check(lib.vmc_act_fwd(ptr(x), ptr(y), x.numel(), act, dt(x), stream()), "act_fwd")
+    return y
+
+
+def act_bwd(x: torch.Tensor, dy: torch.Tensor, act: int) -> torch.Tensor:
+    dx = torch.empty_like(x)
+    check(lib.vmc_act_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), act, dt(x), stream()), "act_bwd")
+    return dx
