@@ -144,7 +144,8 @@ def main():
 
         if not args.no_cpu_baseline:
             from oracle import vit as ovit
-            ncpu = os.cpu_count() or 1
+            # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribes
+            ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
             torch.set_num_threads(ncpu)
             nf = args.cpu_frames
             pix = ovit.normalize_u8(frames[:nf].cpu())

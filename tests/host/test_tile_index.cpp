@@ -189,6 +189,53 @@ static void test_attention(int NT, int N) {
   }
 }
 
+
+// 8-phase kernel: 4 half-tile slots (A0, A1, B0, B1) of one K tile, 8 waves as 2 x 4
+static void test_gemm8() {
+  std::vector<e16> A(256 * 64), W(256 * 64);
+  for (auto& x : A) x = (e16)(rand() % 7 - 3);
+  for (auto& x : W) x = (e16)(rand() % 7 - 3);
+  std::vector<uint8_t> slot[4];  // A0 A1 B0 B1
+  for (auto& s : slot) s.assign(16384, 0xEE);
+  for (int tid = 0; tid < 512; ++tid)
+    for (int i = 0; i < 2; ++i) {
+      int row, ch;
+      stage_src_x(i * 512 + tid, row, ch);
+      memcpy(&slot[0][(size_t)(i * 512 + tid) * 16], &A[row * 64 + ch * 8], 16);
+      memcpy(&slot[1][(size_t)(i * 512 + tid) * 16], &A[(128 + row) * 64 + ch * 8], 16);
+      stage_src_w8(i * 512 + tid, row, ch);
+      memcpy(&slot[2][(size_t)(i * 512 + tid) * 16], &W[row * 64 + ch * 8], 16);
+      memcpy(&slot[3][(size_t)(i * 512 + tid) * 16], &W[(128 + row) * 64 + ch * 8], 16);
+    }
+  for (int wave = 0; wave < 8; ++wave) {
+    const int wm = wave >> 2, wn = wave & 3;
+    for (int mh = 0; mh < 2; ++mh) for (int nh = 0; nh < 2; ++nh)
+      for (int mt = 0; mt < 4; ++mt) for (int nt = 0; nt < 2; ++nt) {
+        long acc[64][4]; memset(acc, 0, sizeof acc);
+        for (int kk = 0; kk < 2; ++kk) {
+          Frag wf[64], xf[64]; int xaddr[64], waddr[64];
+          for (int l = 0; l < 64; ++l) {
+            const int r = l & 15, q = l >> 4;
+            xaddr[l] = lds_off_x(64 * wm + r, 4 * kk + q) + mt * 2048;
+            waddr[l] = lds_off_w8(32 * wn + g8_w_row(r, nt), 4 * kk + q);
+            memcpy(xf[l].v, &slot[mh][xaddr[l]], 16);
+            memcpy(wf[l].v, &slot[2 + nh][waddr[l]], 16);
+          }
+          CHECK(b128_conflict(xaddr) == 1, "g8 X read conflict %d", b128_conflict(xaddr));
+          CHECK(b128_conflict(waddr) == 1, "g8 W read conflict %d", b128_conflict(waddr));
+          mfma16(wf, xf, acc);
+        }
+        for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
+          const int r = l & 15, q = l >> 4;
+          const int row = 128 * mh + 64 * wm + 16 * mt + r, col = 128 * nh + 32 * wn + 8 * q + 4 * nt + j;
+          long ref = 0;
+          for (int k = 0; k < 64; ++k) ref += (long)A[row * 64 + k] * W[col * 64 + k];
+          CHECK(acc[l][j] == ref, "g8 wave %d mh %d nh %d mt %d nt %d lane %d j %d", wave, mh, nh, mt, nt, l, j);
+        }
+      }
+  }
+}
+
 static void test_xcd_remap() {
   for (int nwg : {1, 7, 8, 9, 63, 64, 100, 1028, 3084}) {
     std::set<int> seen;
@@ -202,6 +249,7 @@ int main() {
   test_gemm(8, 2, 4);
   test_gemm(4, 2, 2);
   test_gemm(2, 2, 1);
+  test_gemm8();
   test_attention(18, 257);
   test_attention(4, 50);
   test_attention(2, 17);

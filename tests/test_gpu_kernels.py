@@ -29,7 +29,8 @@ def _ints(shape, lo, hi, seed):
 @pytest.mark.parametrize("M,N,K", [
     (256, 256, 64), (512, 1024, 128),          # whole 256x256 tiles (identity-free, asymmetric W)
     (65792 // 16, 1024, 1024),                 # 4112 rows: 128x128 config with a ragged last row tile
-    (3333, 4096, 128), (3100, 3072, 64),       # 256x256 config (>= 192 tiles), ragged M, odd and single K tile
+    (3333, 4096, 128), (3100, 3072, 64),       # 256x256 tiles (>= 192): 8-phase kernel (K % 128 == 0) / two-stage kernel
+    (16448, 1024, 1024), (3333, 4100, 256), (65792, 1024, 128),   # 8-phase: many K tiles, ragged N, the ViT-L/14 row count
     (300, 140, 64), (50, 768, 192), (8, 384, 768), (129, 2304, 768), (1000, 64, 3072), (16448, 256, 640),
 ])
 def test_linear_exact_integers(ops, dtype, M, N, K):
@@ -47,8 +48,9 @@ def test_linear_exact_integers(ops, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("res_f32,out_f32", [(True, True), (False, False), (True, False)])
-def test_linear_epilogue(ops, dtype, act, res_f32, out_f32):
-    M, N, K = 333, 200, 128
+@pytest.mark.parametrize("shape", [(333, 200, 128), (3900, 4096, 256)], ids=["small", "g8"])
+def test_linear_epilogue(ops, dtype, act, res_f32, out_f32, shape):
+    M, N, K = shape
     g = torch.Generator().manual_seed(5)
     a = torch.randn(M, K, generator=g).to(dtype)
     w = (torch.randn(N, K, generator=g) * 0.2).to(dtype)

@@ -5,21 +5,7 @@
 // address and on the ds_read_b128 address), one vmcnt(0)+barrier per K tile with the next tile's DMA
 // in flight under the MFMAs.  Operands are passed to v_mfma_f32_16x16x32 as (W, X) so each lane owns
 // 16 consecutive output columns of one row -> bias/residual/stores are 16-byte vectors.
-#include "common.h"
-
-struct GemmArgs {
-  const char* A;
-  const char* W;
-  const float* bias;
-  const char* res;
-  char* C;
-  int M, N, K;
-  int lda, ldw, ldc, ldres;
-  float alpha;
-  int out_f32, res_f32;
-  int out_row_group, res_row_mod;
-  int tiles_m, tiles_n;
-};
+#include "gemm_common.h"
 
 template <int MT, int WM, int WN>
 struct GemmCfg {
@@ -263,6 +249,11 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   g.alpha = alpha; g.out_f32 = (out_dtype == VMC_F32); g.res_f32 = (res_dtype == VMC_F32);
   g.out_row_group = out_row_group; g.res_row_mod = res_row_mod;
   g.tiles_m = g.tiles_n = 0;
+  // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
+  // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
+  static const bool use_g8 = []() { const char* e = getenv("VMC_GEMM8"); return !(e && e[0] == '0'); }();
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (use_g8 && t256 >= 192 && (K % 128) == 0) return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
   if (dtype16 == VMC_BF16) return launch_act<BF16>(g, act, (hipStream_t)stream);
   return launch_act<F16>(g, act, (hipStream_t)stream);
 }

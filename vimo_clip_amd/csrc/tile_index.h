@@ -35,6 +35,18 @@ VMC_HD int lds_off_w(int row, int chunk) { return row * 128 + ((chunk ^ swz_w(ro
 VMC_HD int gemm_w_row(int r, int nt) { return 16 * (r >> 2) + 4 * nt + (r & 3); }
 VMC_HD int gemm_c_col(int q, int nt, int j) { return 16 * q + 4 * nt + j; }
 
+// ---- 8-phase GEMM (256x256x64 tile as 4 half-tile slots of 128 rows per K tile) ------------------
+// Wave (wm, wn) of the 2x4 wave grid owns rows {128*mh + 64*wm + [0,64)} and cols {128*nh + 32*wn + [0,32)},
+// mh, nh in {0,1}: 64 rows of EACH A half-tile and 32 columns of EACH B half-tile, so every wave needs
+// half-tile A0/B0 in phase 0, B1 in phase 1, A1 in phase 2 (uniform deadlines for the LDS-DMA pipeline).
+//   X fragment (mh, mt, kk): slot A_mh, row 64*wm + 16*mt + r            (mt = 0..3)
+//   W fragment (nh, nt, kk): slot B_nh, row 32*wn + g8_w_row(r, nt)      (nt = 0..1)
+//   acc[mh][mt][nh][nt][j] = C[128*mh + 64*wm + 16*mt + r][128*nh + 32*wn + 8*q + 4*nt + j]
+VMC_HD int g8_w_row(int r, int nt) { return 8 * (r >> 2) + 4 * nt + (r & 3); }
+VMC_HD int swz_w8(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+VMC_HD int lds_off_w8(int row, int chunk) { return row * 128 + ((chunk ^ swz_w8(row)) << 4); }
+VMC_HD void stage_src_w8(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w8(row); }
+
 // Staging: 16-B chunk `idx` (LDS order) of an operand tile -> (row, logical chunk) to fetch.
 VMC_HD void stage_src_x(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_x(row); }
 VMC_HD void stage_src_w(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w(row); }
