@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of vmc_linear on the shapes of the ViT-L/14 encoder (and square reference shapes).
+    python tools/gemm_bench.py [--shapes M,N,K ...] [--iters 20] [--dtype bf16]
+Random (never zero) operands; HIP events on the launch stream; prints TFLOP/s per shape."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vimo_clip_amd import ops  # noqa: E402
+
+DEFAULT = ["65792,1024,1024", "65792,3072,1024", "65792,4096,1024", "65792,1024,4096", "8192,8192,8192", "4096,4096,4096"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", nargs="*", default=DEFAULT)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--epilogue", action="store_true", help="bias + QuickGELU + fp32 residual like the encoder")
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    for s in args.shapes:
+        M, N, K = map(int, s.split(","))
+        a = torch.randn(M, K, device="cuda").to(dt)
+        w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        bias = torch.randn(N, device="cuda") if args.epilogue else None
+        for _ in range(3):
+            ops.linear(a, w, bias=bias, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.linear(a, w, bias=bias, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        print(f"M={M} N={N} K={K} {args.dtype}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

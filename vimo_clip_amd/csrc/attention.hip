@@ -12,7 +12,7 @@
 //   permuted (tile_index.h attn_pv_key); V^T fragments come from ds_read_b64_tr_b16.
 // ==================================================================================================
 template <typename T, int NT>
-__global__ void __launch_bounds__(256) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKEYS = 16 * NT;
@@ -42,12 +42,21 @@ __global__ void __launch_bounds__(256) attn_vit_kernel(const uint16_t* __restric
 
   const float c2 = scale * 1.4426950408889634f;
   const int nqt = (N + 15) >> 4;
+  // per-lane LDS offsets; tile index / k-step only add compile-time constants (keeps address VGPRs low)
+  const int koff0 = lds_off_x(r, q), koff1 = lds_off_x(r, 4 + q);
+  int voff[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_off_v(4 * q + (r >> 2), 2 * dt + ((r & 3) >> 1)) + (r & 1) * 8;
+  uint4 qnext[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(wave * 16 + r, N - 1) * ld + (4 * kk + q) * 8);
   for (int qt = wave; qt < nqt; qt += 4) {
     const int qrow = qt * 16 + r;
-    const int qrow_ld = min(qrow, N - 1);
-    uint4 qf[2];
+    uint4 qf[2] = {qnext[0], qnext[1]};
+    if (qt + 4 < nqt) {  // prefetch the next query tile's fragments under this tile's MFMAs
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const uint4*)(base + (size_t)qrow_ld * ld + (4 * kk + q) * 8);
+      for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(qrow + 64, N - 1) * ld + (4 * kk + q) * 8);
+    }
 
     f32x4 s[NT];
 #pragma unroll
@@ -55,7 +64,7 @@ __global__ void __launch_bounds__(256) attn_vit_kernel(const uint16_t* __restric
       s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const uint4 kf = *(const uint4*)(k_lds + lds_off_x(16 * nt + r, 4 * kk + q));
+        const uint4 kf = *(const uint4*)(k_lds + (kk ? koff1 : koff0) + nt * 2048);
         s[nt] = T::mfma16(kf, qf[kk], s[nt]);
       }
     }
@@ -98,12 +107,10 @@ __global__ void __launch_bounds__(256) attn_vit_kernel(const uint16_t* __restric
       pf.w = pack2<T>(s[2 * ks + 1][2], s[2 * ks + 1][3]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        // 4-key x 16-column blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block
-        const int key0 = 32 * ks + 4 * q + (r >> 2);
-        const int chunk = 2 * dt + ((r & 3) >> 1);
-        const int half = (r & 1) * 8;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + lds_off_v(key0, chunk) + half));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + lds_off_v(key0 + 16, chunk) + half));
+        // 4-key x 16-column blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block:
+        // keys 32 ks + 4 q + (r>>2) (+16 for the second block); the swizzle does not depend on ks
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + ks * 4096));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + ks * 4096 + 2048));
         uint4 vf;
         const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
         vf.x = a.x; vf.y = a.y; vf.z = b.x; vf.w = b.y;
