@@ -103,12 +103,15 @@ int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype
 int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y16, float* y32,
                       float* mean, float* rstd, int rows, int D, int ldx, float eps, int x_dtype,
                       int dtype16, void* stream);
-/* dx [rows,D] (f32 or 16-bit per dx_dtype); dgamma/dbeta f32 [D] (overwritten).  dy f32 or 16-bit. */
+/* Backward (autograd of the LayerNorms, train.py:104): dx [rows,D] (f32 or 16-bit per dx_dtype) =
+ * LN'(dy) + add, where `add` (optional, dx's dtype/layout) is the gradient arriving over the residual
+ * branch that forks at x (fused so the fork needs no separate add pass).  dgamma/dbeta f32 [D],
+ * overwritten.  dy f32 or 16-bit.  D <= 2048. */
 size_t vmc_layernorm_bwd_workspace_bytes(int rows, int D);
 int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                      void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
-                      int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx,
+                      int dy_dtype, int x_dtype, int dx_dtype, int dtype16, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4 — ViT self-attention  softmax(Q K^T / sqrt(dh)) V, no mask, head_dim 64 (MFMA, K/V tile in LDS).
@@ -128,18 +131,21 @@ int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int F, int N, 
  *   key_mask u8 [B, Tk], 1 = attend, 0 = padding (the reference's mask_rgb/mask_flow), may be NULL
  *   out 16-bit [(b*Tq+t)*ldo + h*dh + d];  lse f32 [B,H,Tq] optional.
  *   A query row whose keys are all masked yields NaN, as torch does.
+ *   dropout_p > 0 drops attention probabilities after the softmax (nn.MultiheadAttention(dropout=p), train
+ *   mode) with the counter-based keep mask hash(dropout_seed, ((b*H+h)*Tq+t)*Tk+key); the backward must be
+ *   given the same (p, seed).
  */
 int vmc_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* out,
                       float* lse, int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
-                      int dtype16, void* stream);
+                      float dropout_p, uint64_t dropout_seed, int dtype16, void* stream);
 /* Backward of the above (autograd of the MHA core, train.py:104 / TFAM/train_and_eval.py:82): dq, dk, dv
  * 16-bit with their own row strides, fully overwritten.  workspace >= vmc_attention_bwd_workspace_bytes. */
 size_t vmc_attention_bwd_workspace_bytes(int B, int H, int Tq);
 int vmc_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, const void* out,
                       const void* dout, const float* lse, void* dq, void* dk, void* dv,
                       int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
-                      int lddq, int lddk, int lddv, void* workspace, size_t workspace_bytes, int dtype16,
-                      void* stream);
+                      int lddq, int lddk, int lddv, float dropout_p, uint64_t dropout_seed, void* workspace,
+                      size_t workspace_bytes, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Small element-wise / pooling pieces.
@@ -158,6 +164,23 @@ int vmc_mean_pool(const void* x, void* out16, float* out32, int B, int T, int D,
 int vmc_add_sinusoidal_pe(float* x, int B, int T, int D, void* stream);
 /* y = a + alpha * b elementwise, f32. */
 int vmc_axpby_f32(const float* a, const float* b, float* y, size_t n, float alpha, float beta, void* stream);
+/* y = a + b on flat arrays (sum of the two gradients meeting where a tensor is used twice; autograd of
+ * the residual forks, train.py:104); each operand f32 or 16-bit. */
+int vmc_add(const void* a, const void* b, void* y, size_t n, int a_dtype, int b_dtype, int y_dtype, int dtype16,
+            void* stream);
+/* Backward of vmc_mean_pool: dx[b,t,:] = dout[b,:] / T. */
+int vmc_mean_pool_bwd(const void* dout, void* dx, int B, int T, int D, int dout_dtype, int dx_dtype, int dtype16,
+                      void* stream);
+/* Training-path token assembly of K1 (class token concat + positional embedding, OpenAI clip
+ * VisionTransformer.forward): x[f,0,:] = cls + pos[0]; x[f,1+p,:] = xp[f*(N-1)+p,:] + pos[1+p].
+ * xp 16-bit [F*(N-1), D]; cls f32 [D]; pos f32 [N,D]; x [F*N, D] f32 or 16-bit. */
+int vmc_assemble_tokens(const void* xp, const float* cls, const float* pos, void* x, int F, int N, int D,
+                        int x_dtype, int dtype16, void* stream);
+/* Inverted dropout, y = x * keep/(1-p), keep(i) = hash(seed, i) >= p (nn.Dropout of
+ * TFAM/models/AMO_CLIP.py:27-35,84).  Stateless: the backward applies the same call to dy. */
+int vmc_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int x_dtype, int dtype16, void* stream);
+/* y = x * scale[0], the scale read from device memory (the scalar gradient arriving at a loss node). */
+int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, const float* scale, void* stream);
 /* f32 <-> 16-bit casts on flat arrays. */
 int vmc_cast_f32_to_16(const float* x, void* y, size_t n, int dtype16, void* stream);
 int vmc_cast_16_to_f32(const void* x, float* y, size_t n, int dtype16, void* stream);

@@ -1,0 +1,236 @@
+"""GPU: TFAM (AMO_CLIP), losses, student model and the training steps (HIP path through the C ABI) against
+the golden fixtures recorded from the reference (losses.py, TFAM/models/AMO_CLIP.py) and the CPU oracle.
+
+Tolerances: BASELINE.json asks for "TFAM logits within 1e-3 fp16": f16 compute -> |d| <= 1e-3 * max(1, max|ref|);
+bf16 (3 fewer mantissa bits) -> 8e-3.  Losses are fp32 kernels: 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden as mg
+from oracle import student as ostudent
+from oracle import tfam as otfam
+from oracle import vit as ovit
+from vimo_clip_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def _tfam(c, dtype, **extra):
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    kw = mg.tfam_mode_kwargs(c["mode"])
+    m = AMO_CLIP(d_model=c["D"], nhead=c["H"], num_layers=c["L"], dim_feedforward=c["ff"], num_classes=c["C"], use_pe=c["pe"],
+                 dropout=extra.pop("dropout", 0.0), mlp_dropout=extra.pop("mlp_dropout", 0.0), device="cuda", compute_dtype=dtype, **kw).cuda()
+    m.load_state_dict(synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"]), strict=True)
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("c", mg.TFAM_CASES, ids=lambda c: c["name"])
+def test_tfam_eval_logits_vs_reference(golden, c, dtype):
+    m = _tfam(c, dtype).eval()
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    rgb_d, mot_d = rgb.cuda(), mot.cuda()
+    with torch.no_grad():
+        y = m(rgb_d, mot_d, mask_rgb=mr.cuda(), mask_flow=mf.cuda()).cpu()
+    ref = torch.from_numpy(golden["tfam"][f"{c['name']}/logits"])
+    err = (y - ref).abs().max().item()
+    print(f"tfam {c['name']} {dtype}: max abs err {err:.3e} (|ref|max {ref.abs().max():.2f})")
+    assert err <= TOL[dtype] * max(1.0, ref.abs().max().item())
+    if c["pe"]:     # the reference adds the positional encoding in place to the caller's tensors (AMO_CLIP.py:133-134)
+        torch.testing.assert_close(rgb_d.cpu(), rgb + otfam.positional_encoding(rgb.shape[1], c["D"]), atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["cross_d512", "rgb_only", "concat_embed", "cross_d768_ragged_pe"])
+def test_tfam_train_loss_and_grads_vs_reference(golden, name):
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    c = next(x for x in mg.TFAM_CASES if x["name"] == name)
+    m = _tfam(c, torch.float16).train()
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    y = synth.multi_hot_labels(c["seed"], "labels", c["B"], c["C"]).cuda()
+    logits = m(rgb.cuda(), mot.cuda(), mask_rgb=mr.cuda(), mask_flow=mf.cuda())
+    loss = bce_with_logits_loss(logits, y)
+    loss.backward()
+    g = golden["tfam"]
+    assert abs(loss.item() - float(g[f"{name}/train_loss"])) <= 2e-3 * abs(float(g[f"{name}/train_loss"]))
+    params = dict(m.named_parameters())
+    for k in ("classifier.4.weight", "classifier.1.bias", "layers.0.ffn.0.bias", "layers.0.self_attn.in_proj_bias", "layers.0.norm_self.weight"):
+        ref = torch.from_numpy(g[f"{name}/grad/{k}"])
+        got = params[k].grad.cpu()
+        denom = ref.abs().max().item() + 1e-12
+        rel = (got - ref).abs().max().item() / denom
+        print(f"{name} grad {k}: rel-to-max err {rel:.3e}")
+        assert rel <= 3e-2, (k, rel)
+    used = {id(p) for p in m.used_parameters()}
+    for n, p in m.named_parameters():
+        assert (p.grad is not None) == (id(p) in used), n      # exactly the statically-known used set gets gradients
+
+
+def test_tfam_dropout_train_mode_statistics():
+    # dropout > 0: counter-based masks in the kernels; same seed -> same logits; mean logits close to eval
+    c = mg.TFAM_CASES[0]
+    m = _tfam(c, torch.float16, dropout=0.1, mlp_dropout=0.3).train()
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    args = (rgb.cuda(), mot.cuda())
+    kw = dict(mask_rgb=mr.cuda(), mask_flow=mf.cuda())
+    import vimo_clip_amd.TFAM.models.AMO_CLIP as mod
+    import itertools
+    mod._seed_counter = itertools.count(1)
+    a = m(*args, **kw)
+    mod._seed_counter = itertools.count(1)
+    b = m(*args, **kw)
+    assert torch.equal(a, b)
+    c2 = m(*args, **kw)
+    assert not torch.equal(a, c2)
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.used_parameters())
+
+
+@pytest.mark.parametrize("c", mg.LOSS_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("mode", ["cosine", "mse"])
+def test_distillation_loss_vs_reference(golden, c, mode):
+    from vimo_clip_amd.losses import distillation_loss
+    s, t = mg.loss_inputs(c)
+    s = s.cuda().requires_grad_(True)
+    # the teacher slice of train.py:98: [B, T+1, E][:, :-1]
+    t_full = torch.cat([t, torch.zeros(c["B"], 1, c["E"])], dim=1).cuda()
+    loss = distillation_loss(s, t_full[:, :-1, :], mode=mode)
+    (3.0 * loss).backward()
+    g = golden["losses"]
+    np.testing.assert_allclose(loss.item(), g[f"{c['name']}/{mode}/loss"], rtol=1e-5, atol=1e-7)
+    ref = 3.0 * g[f"{c['name']}/{mode}/grad"]
+    np.testing.assert_allclose(s.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+    with pytest.raises(ValueError, match="Unsupported mode"):
+        distillation_loss(s, t_full[:, :-1, :], mode="l1")
+
+
+@pytest.mark.parametrize("c", mg.BCE_CASES, ids=lambda c: c["name"])
+def test_classification_loss_vs_reference(golden, c):
+    from vimo_clip_amd.losses import classification_loss
+    x, y = mg.bce_inputs(c)
+    x = x.cuda().requires_grad_(True)
+    loss = classification_loss(x, y.cuda(), positive_weight=c["pw"])
+    loss.backward()
+    g = golden["losses"]
+    np.testing.assert_allclose(loss.item(), g[f"{c['name']}/loss"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{c['name']}/grad"], rtol=1e-4, atol=1e-8)
+
+
+def _student(name, seed, dtype):
+    from vimo_clip_amd.models import FlowStudentModel
+    m = FlowStudentModel(name, device="cuda", num_classes=140, alpha=0.1, compute_dtype=dtype)
+    sd = synth.student_state_dict(name, seed)
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+@pytest.mark.parametrize("name,B,T", [("ViT-tiny/32", 3, 5), ("ViT-B/32", 2, 4)])
+def test_student_forward_vs_oracle(name, B, T):
+    R, H = synth.VIT_GEOMETRY[name][0], synth.VIT_GEOMETRY[name][4]
+    m, sd = _student(name, 61, torch.float16)
+    vids = synth.randint_u8(61, "vids", (B, T, 3, R, R))
+    with torch.no_grad():
+        emb, emb_d, logits = m.eval()(vids.cuda())
+    r_emb, r_emb_d, r_logits = ostudent.student_forward(sd, vids, H, alpha=0.1, wrap_quirk=True)
+    for got, ref, nm in ((emb, r_emb, "emb"), (emb_d, r_emb_d, "emb_distill"), (logits, r_logits, "logits")):
+        err = (got.cpu() - ref).abs().max().item()
+        print(f"student {name} {nm}: max abs err {err:.3e} scale {ref.abs().max():.2f}")
+        assert got.shape == ref.shape and err <= 2e-3 * max(1.0, ref.abs().max().item())
+    # float inputs holding 0..255 values take the same path as u8 (student_model.py:74)
+    with torch.no_grad():
+        emb2, _, _ = m(vids.float().cuda())
+    assert torch.equal(emb, emb2)
+
+
+def test_student_train_step_vs_oracle_autograd():
+    """One full student step on ViT-tiny/32: loss = cosine distill + BCE(pos_weight 9) (train.py:95-107);
+    gradients of every parameter vs torch autograd through the fp32 oracle; then Adam vs the oracle update."""
+    from vimo_clip_amd.losses import classification_loss, distillation_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    name, B, T = "ViT-tiny/32", 4, 5
+    R, H = synth.VIT_GEOMETRY[name][0], synth.VIT_GEOMETRY[name][4]
+    m, sd = _student(name, 71, torch.float16)
+    m.train()
+    vids = synth.randint_u8(71, "vids", (B, T, 3, R, R))
+    teacher = synth.normal(71, "teacher", (B, T + 1, 64))
+    labels = synth.multi_hot_labels(71, "labels", B, 140)
+    arena = GradArena(m.parameters())
+    opt = FusedAdam(arena, lr=1e-3)
+    emb, emb_d, logits = m(vids.cuda())
+    loss = distillation_loss(emb_d, teacher.cuda()[:, :-1, :], mode="cosine") + classification_loss(logits, labels.cuda(), positive_weight=9)
+    loss.backward()
+    # ---- oracle ----
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, oe_d, ol = ostudent.student_forward(sdo, vids, H, alpha=0.1, wrap_quirk=True)
+    oloss = ostudent.distillation_loss(oe_d, teacher[:, :-1, :], "cosine") + ostudent.classification_loss(ol, labels, 9)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) <= 2e-3 * abs(oloss.item())
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = sdo[k].grad
+        got = p.grad.cpu()
+        rel = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 5e-2, (k, rel)
+    print(f"student step: loss {loss.item():.5f} vs {oloss.item():.5f}; worst grad rel-to-max err {worst:.3e}")
+    # ---- Adam step (train.py:66,107) with the HIP gradients on both sides ----
+    before = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    opt.step()
+    for k, p in m.named_parameters():
+        want, _, _ = ostudent.adam_step(before[k], grads[k], torch.zeros_like(before[k]), torch.zeros_like(before[k]), 1, 1e-3)
+        torch.testing.assert_close(p.detach().cpu(), want, atol=1e-7, rtol=1e-5)
+    # the 16-bit weight copies were invalidated: a second forward sees the updated weights
+    emb2, _, _ = m(vids.cuda())
+    assert not torch.equal(emb2, emb)
+
+
+def test_adamw_matches_torch():
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    ps = [torch.nn.Parameter(synth.normal(5, f"p{i}", s).cuda()) for i, s in enumerate([(33, 7), (129,), (64, 64)])]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    arena = GradArena(ps)
+    opt = FusedAdam(arena, lr=1e-4, weight_decay=0.1, decoupled=True)
+    topt = torch.optim.AdamW(ref, lr=1e-4, weight_decay=0.1)
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = synth.normal(step, f"g{i}", tuple(p.shape))
+            p.grad.copy_(g.cuda())
+            r.grad = g.clone()
+        opt.step()
+        topt.step()
+    for p, r in zip(ps, ref):
+        torch.testing.assert_close(p.detach().cpu(), r.detach(), atol=1e-7, rtol=2e-6)
+    assert abs(arena.grad_norm().item() - torch.cat([r.grad.reshape(-1) for r in ref]).norm().item()) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,masked", [(3, 8, 16, 15, 96, True), (2, 8, 16, 16, 64, False), (2, 2, 50, 50, 64, False)])
+def test_attention_backward_vs_torch(B, H, Tq, Tk, dh, masked):
+    from vimo_clip_amd import autograd_ops as ag
+    D = H * dh
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B * Tq, D, generator=g).to(torch.float16)
+    kv = torch.randn(B * Tk, 2 * D, generator=g).to(torch.float16)
+    do = torch.randn(B * Tq, D, generator=g).to(torch.float16)
+    mask = None
+    if masked:
+        lens = torch.randint(1, Tk + 1, (B,), generator=g)
+        mask = (torch.arange(Tk)[None] < lens[:, None])
+    qd, kvd = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    out = ag.CrossAttnFn.apply(qd, kvd, mask.to(torch.uint8).cuda() if masked else None, B, Tq, Tk, H)
+    out.backward(do.cuda())
+    qf = q.float().requires_grad_(True)
+    kvf = kv.float().requires_grad_(True)
+    qh = qf.view(B, Tq, H, dh).transpose(1, 2)
+    kh = kvf[:, :D].reshape(B, Tk, H, dh).transpose(1, 2)
+    vh = kvf[:, D:].reshape(B, Tk, H, dh).transpose(1, 2)
+    s = (qh * dh ** -0.5) @ kh.transpose(-1, -2)
+    if masked:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Tq, D)
+    ref.backward(do.float())
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), atol=3e-3, rtol=3e-3)
+    torch.testing.assert_close(qd.grad.float().cpu(), qf.grad, atol=5e-3, rtol=2e-2)
+    torch.testing.assert_close(kvd.grad.float().cpu(), kvf.grad, atol=5e-3, rtol=2e-2)

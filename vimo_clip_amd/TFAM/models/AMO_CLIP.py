@@ -1,0 +1,284 @@
+"""TFAM fusion block + multi-label head on libvmc — drop-in for TFAM/models/AMO_CLIP.py.
+
+``AttentionLayer`` / ``AMO_CLIP`` keep the reference's constructor and forward signatures and its
+``state_dict`` keys (``layers.{i}.self_attn.in_proj_weight|in_proj_bias|out_proj.*``, ``layers.{i}.cross_attn.*``,
+``layers.{i}.ffn.{0,3}.*``, ``layers.{i}.norm_{self,cross,ffn}.*``, ``classifier.{0,1,4}.*``,
+``projection_layer.*``; TFAM/models/AMO_CLIP.py:19-34,81-86) so its checkpoints load ``strict=True``.
+
+Reference behaviours kept on purpose: the mean-pool runs over ALL T rows
+including padded ones (:170); with ``use_pe`` the positional encoding is added IN PLACE to the caller's
+tensors (:133-134); the FFN activation is ReLU whatever ``activation`` says (:13,81), the classifier uses
+exact GELU; in cross-attention mode every layer attends the same raw motion tokens.
+
+Data layout: tokens are flattened to [B*T, D]; LayerNorm outputs are produced in fp32 (residual operand)
+and cast once to the compute dtype (GEMM operand); the residual sums are formed in fp32 inside the GEMM
+epilogues.  Dropout (train mode) uses counter-based masks inside the kernels.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import autograd_ops as ag
+from ... import ops
+from ...clip_vit import _Lin, _LN
+
+_seed_counter = itertools.count(1)
+
+
+class _MHA(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, d_model, num_heads, dropout):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = d_model, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = _Lin(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.kaiming_uniform_(self.out_proj.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder that keeps nn.Sequential indices aligned with the reference."""
+
+    def forward(self, x):
+        return x
+
+
+def _linear_init(lin):
+    nn.init.kaiming_uniform_(lin.weight, a=math.sqrt(5))
+    bound = 1 / math.sqrt(lin.weight.shape[1])
+    nn.init.uniform_(lin.bias, -bound, bound)
+    return lin
+
+
+class AttentionLayer(nn.Module):
+    def __init__(self, d_model: int, num_heads: int, dim_feedforward: int, dropout: float = 0.1, activation: str = "relu"):
+        super().__init__()
+        assert d_model % num_heads == 0, f"d_model ({d_model}) debe ser divisible por num_heads ({num_heads})"
+        self.self_attn = _MHA(d_model, num_heads, dropout)
+        self.cross_attn = _MHA(d_model, num_heads, dropout)
+        # Sequential(Linear, act, Dropout, Linear, Dropout): parameters at indices 0 and 3 (:23-29)
+        self.ffn = nn.Sequential(_linear_init(_Lin(d_model, dim_feedforward)), _Slot(), _Slot(),
+                                 _linear_init(_Lin(dim_feedforward, d_model)), _Slot())
+        self.ffn_act = ops.ACT_GELU_ERF if activation == "gelu" else ops.ACT_RELU
+        self.norm_self, self.norm_cross, self.norm_ffn = _LN(d_model), _LN(d_model), _LN(d_model)
+        self.p = dropout
+        self.d_model, self.num_heads = d_model, num_heads
+
+    # x32: fp32 [B*T, D] tokens (residual operand); returns the next fp32 token matrix
+    def run(self, x32, B, T, dt16, mask_u8, cross16=None, Tk=0, cross_mask_u8=None, seed_fn=None):
+        H, D = self.num_heads, self.d_model
+        tr = self.training
+        p = self.p if tr else 0.0
+        xr, xg = ag.fork(x32, dt16)
+        x16 = ag.cast(xg, dt16)
+        qkv = ag.linear(x16, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
+        o = _SelfAttn.apply(qkv, mask_u8, B, T, H, p, seed_fn() if p > 0 else 0)
+        o = ag.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
+        o = ag.dropout(o, p, tr, seed_fn)
+        y = _add32(xr, o, dt16)
+        x32 = ag.layernorm(y, self.norm_self.weight, self.norm_self.bias, dt16, out_f32=True)
+        if cross16 is not None:
+            xr, xg = ag.fork(x32, dt16)
+            x16 = ag.cast(xg, dt16)
+            W, b = self.cross_attn.in_proj_weight, self.cross_attn.in_proj_bias
+            q = ag.linear(x16, _RowSlice.apply(W, 0, D), _RowSlice.apply(b, 0, D))
+            kv = ag.linear(cross16, _RowSlice.apply(W, D, 3 * D), _RowSlice.apply(b, D, 3 * D))
+            o = _CrossAttn.apply(q, kv, cross_mask_u8, B, T, Tk, H, p, seed_fn() if p > 0 else 0)
+            o = ag.linear(o, self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias)
+            o = ag.dropout(o, p, tr, seed_fn)
+            y = _add32(xr, o, dt16)
+            x32 = ag.layernorm(y, self.norm_cross.weight, self.norm_cross.bias, dt16, out_f32=True)
+        xr, xg = ag.fork(x32, dt16)
+        x16 = ag.cast(xg, dt16)
+        h = ag.linear(x16, self.ffn[0].weight, self.ffn[0].bias, act=self.ffn_act)
+        h = ag.dropout(h, p, tr, seed_fn)
+        f = ag.linear(h, self.ffn[3].weight, self.ffn[3].bias)
+        f = ag.dropout(ag.dropout(f, p, tr, seed_fn), p, tr, seed_fn)     # ffn's own Dropout, then self.dropout (:28,:50)
+        y = _add32(xr, f, dt16)
+        return ag.layernorm(y, self.norm_ffn.weight, self.norm_ffn.bias, dt16, out_f32=True)
+
+
+class _Add32(torch.autograd.Function):
+    """y(f32) = a(f32) + b(16-bit): the residual sum feeding a post-norm LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, a, b, dt16):
+        ctx.meta = (b.dtype, dt16)
+        return ag._add(a, b, torch.float32, dt16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        bdtype, dt16 = ctx.meta
+        dy = dy.contiguous()
+        return dy, ops.cast16(dy, bdtype), None
+
+
+def _add32(a, b, dt16):
+    return _Add32.apply(a, b, dt16)
+
+
+class _RowSlice(torch.autograd.Function):
+    """Rows [lo, hi) of a parameter (the q / kv thirds of in_proj_weight, F.multi_head_attention_forward's
+    ``_in_projection_packed``); the backward writes the slice of the gradient into a zero tensor (or the
+    parameter's arena slot rows) — memory plumbing only."""
+
+    @staticmethod
+    def forward(ctx, w, lo, hi):
+        ctx.w, ctx.lo, ctx.hi = w, lo, hi
+        return w.detach()[lo:hi]
+
+    @staticmethod
+    def backward(ctx, g):
+        w, lo, hi = ctx.w, ctx.lo, ctx.hi
+        slot = getattr(w, "_vmc_grad", None)
+        if slot is not None:
+            slot[lo:hi].copy_(g.view(slot[lo:hi].shape))
+            return None, None, None
+        full = torch.zeros_like(w)
+        full[lo:hi].copy_(g.view(full[lo:hi].shape))
+        return full, None, None
+
+
+class _SelfAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, mask, B, T, H, p, seed):
+        D = qkv.shape[1] // 3
+        dh = D // H
+        out, lse = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mask, B, H, T, T, dh, want_lse=True,
+                                 dropout_p=p, dropout_seed=seed)
+        ctx.save_for_backward(qkv, out, lse, mask)
+        ctx.meta = (B, T, H, D, dh, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, mask = ctx.saved_tensors
+        B, T, H, D, dh, p, seed = ctx.meta
+        dout = ops.cast16(dout.contiguous(), qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        ag._attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mask, out, dout, lse,
+                     dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, T, T, dh, p, seed)
+        return dqkv, None, None, None, None, None, None
+
+
+class _CrossAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, mask, B, Tq, Tk, H, p, seed):
+        D = q.shape[1]
+        dh = D // H
+        out, lse = ops.attention(q, kv[:, :D], kv[:, D:], mask, B, H, Tq, Tk, dh, want_lse=True, dropout_p=p, dropout_seed=seed)
+        ctx.save_for_backward(q, kv, out, lse, mask)
+        ctx.meta = (B, Tq, Tk, H, D, dh, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, mask = ctx.saved_tensors
+        B, Tq, Tk, H, D, dh, p, seed = ctx.meta
+        dout = ops.cast16(dout.contiguous(), q.dtype)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ag._attn_bwd(q, kv[:, :D], kv[:, D:], mask, out, dout, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Tq, Tk, dh, p, seed)
+        return dq, dkv, None, None, None, None, None, None, None
+
+
+class AMO_CLIP(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, use_cross_attention=True,
+                 use_pe=False, use_only_rgb=False, use_only_flow=False, concat_dim=1, dropout=0.1, mlp_dropout=0.3,
+                 device="cuda", compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.use_cross_attention, self.use_pe = use_cross_attention, use_pe
+        self.use_only_rgb, self.use_only_flow, self.concat_dim = use_only_rgb, use_only_flow, concat_dim
+        self.d_model, self.device, self.nhead = d_model, device, nhead
+        self.compute_dtype = compute_dtype
+        self.mlp_dropout = mlp_dropout
+        self.layers = nn.ModuleList([AttentionLayer(d_model, nhead, dim_feedforward, dropout=dropout) for _ in range(num_layers)])
+        # Sequential(LayerNorm, Linear, GELU, Dropout, Linear): parameters at indices 0, 1, 4 (:84)
+        self.classifier = nn.Sequential(_LN(d_model), _linear_init(_Lin(d_model, d_model // 2)), _Slot(), _Slot(),
+                                        _linear_init(_Lin(d_model // 2, num_classes)))
+        self.projection_layer = _linear_init(_Lin(2 * d_model, d_model))
+        self._seed_base = 0x5EED
+
+    def set_dropout_seed(self, seed: int):
+        """Per-rank / per-run base seed of the counter-based dropout masks."""
+        self._seed_base = int(seed)
+
+    def _next_seed(self):
+        return (self._seed_base << 20) ^ next(_seed_counter)
+
+    def positional_encoding(self, seq_len):
+        """Sinusoidal table [seq_len, d_model] (:88-97), produced by the same kernel that adds it."""
+        pe = torch.zeros(1, seq_len, self.d_model, device=self.device)
+        return ops.add_sinusoidal_pe_(pe)[0]
+
+    def used_parameters(self):
+        """Parameters that receive a gradient in the configured fusion mode (the DDP all-reduce set;
+        SURVEY.md §7 'DDP with unused parameters')."""
+        cross = self.use_cross_attention and not (self.use_only_rgb or self.use_only_flow)
+        proj = (not self.use_only_rgb and not self.use_only_flow and not self.use_cross_attention and self.concat_dim == -1)
+        out = []
+        for n, p in self.named_parameters():
+            if ".cross_attn." in n or ".norm_cross." in n:
+                if cross:
+                    out.append(p)
+            elif n.startswith("projection_layer."):
+                if proj:
+                    out.append(p)
+            else:
+                out.append(p)
+        return out
+
+    def forward(self, rgb_emb, motion_emb, mask_rgb=None, mask_flow=None):
+        dt16, D = self.compute_dtype, self.d_model
+        dev = self.device
+        rgb_emb = rgb_emb if rgb_emb.is_cuda else rgb_emb.to(dev)
+        motion_emb = motion_emb if motion_emb.is_cuda else motion_emb.to(dev)
+        if self.use_pe:                                   # in place on the caller's tensors, as the reference (:133-134)
+            ops.add_sinusoidal_pe_(rgb_emb)
+            ops.add_sinusoidal_pe_(motion_emb)
+        B = rgb_emb.shape[0]
+        m_rgb = mask_rgb.to(device=dev, dtype=torch.uint8).contiguous() if mask_rgb is not None else None
+        m_flow = mask_flow.to(device=dev, dtype=torch.uint8).contiguous() if mask_flow is not None else None
+        seed_fn = self._next_seed
+
+        def flat(t):
+            return t.contiguous().float().view(-1, t.shape[-1])
+
+        if self.use_only_rgb:
+            x, T, m = flat(rgb_emb), rgb_emb.shape[1], m_rgb
+            for layer in self.layers:
+                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+        elif self.use_only_flow:
+            x, T, m = flat(motion_emb), motion_emb.shape[1], m_flow
+            for layer in self.layers:
+                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+        elif self.use_cross_attention:
+            x, T, Tk = flat(rgb_emb), rgb_emb.shape[1], motion_emb.shape[1]
+            cross16 = ag.cast(flat(motion_emb), dt16)
+            for layer in self.layers:
+                x = layer.run(x, B, T, dt16, m_rgb, cross16=cross16, Tk=Tk, cross_mask_u8=m_flow, seed_fn=seed_fn)
+        else:
+            rgb_cut = rgb_emb[:, :-1, :]
+            m_cut = m_rgb[:, :-1] if m_rgb is not None else None
+            if self.concat_dim == 1:
+                xcat = torch.cat([rgb_cut, motion_emb], dim=1)                 # token concat: memory plumbing
+                m = torch.cat([m_cut, m_flow], dim=1).contiguous() if m_cut is not None else None
+                x, T = flat(xcat), xcat.shape[1]
+            else:
+                xcat = torch.cat([rgb_cut, motion_emb], dim=-1)
+                T = xcat.shape[1]
+                x = ag.linear(ag.cast(flat(xcat), dt16), self.projection_layer.weight, self.projection_layer.bias, out_f32=True)
+                m = m_flow
+            for layer in self.layers:
+                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+        pooled = ag.MeanPoolFn.apply(x, B, T, dt16, True)                                      # [B, D] f32, all T rows
+        h = ag.layernorm(pooled, self.classifier[0].weight, self.classifier[0].bias, dt16)
+        h = ag.linear(h, self.classifier[1].weight, self.classifier[1].bias, act=ops.ACT_GELU_ERF)
+        h = ag.dropout(h, self.mlp_dropout, self.training, seed_fn)
+        return ag.linear(h, self.classifier[4].weight, self.classifier[4].bias, out_f32=True)

@@ -32,11 +32,16 @@ SIGNATURES = {
     "vmc_colsum": (I, [P, P, I, I, I, I, P, Z, P]),
     "vmc_layernorm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "vmc_layernorm_bwd_workspace_bytes": (Z, [I, I]),
-    "vmc_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "vmc_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "vmc_scale_by_device_scalar": (I, [P, P, Z, P, P]),
+    "vmc_add": (I, [P, P, P, Z, I, I, I, I, P]),
+    "vmc_mean_pool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "vmc_assemble_tokens": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vmc_dropout": (I, [P, P, Z, F, ctypes.c_uint64, I, I, P]),
     "vmc_attention_vit_fwd": (I, [P, P, P, I, I, I, I, P]),
-    "vmc_attention_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_attention_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, ctypes.c_uint64, I, P]),
     "vmc_attention_bwd_workspace_bytes": (Z, [I, I, I]),
-    "vmc_attention_bwd": (I, [P] * 10 + [I] * 12 + [P, Z, I, P]),
+    "vmc_attention_bwd": (I, [P] * 10 + [I] * 12 + [F, ctypes.c_uint64, P, Z, I, P]),
     "vmc_set_class_rows": (I, [P, P, P, I, I, Z, I, I, P]),
     "vmc_act_fwd": (I, [P, P, Z, I, I, P]),
     "vmc_act_bwd": (I, [P, P, P, Z, I, I, P]),

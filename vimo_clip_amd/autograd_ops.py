@@ -1,0 +1,394 @@
+"""torch.autograd.Function wrappers over the libvmc kernels (K8: autograd of the hot path, train.py:104,
+TFAM/train_and_eval.py:82).
+
+Every forward and backward body is libvmc kernels only.  Tensors that are used twice go through an
+explicit fork (``LayerNormFn(passthrough=True)`` fuses the sum of the two gradients into the LayerNorm
+backward kernel; ``fork`` sums with vmc_add), so autograd itself never has to add gradients with ATen ops.
+Parameter gradients are written straight into ``param._vmc_grad`` (a view into a flat gradient arena,
+see optim.GradArena) when that attribute exists; otherwise they are returned to autograd.
+
+Activations are 2-D ``[rows, features]`` contiguous tensors in the compute dtype (bf16/f16) unless a
+function says otherwise; parameters are fp32 masters whose 16-bit copies are cached per version.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import check, dt, lib, ptr, stream
+
+ACT_NONE = ops.ACT_NONE
+
+
+# ------------------------------------------------------------------------------------------------
+# 16-bit weight copies
+# ------------------------------------------------------------------------------------------------
+class _WeightCache:
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False):
+        if not isinstance(p, torch.nn.Parameter):      # temporaries (e.g. row slices of in_proj_weight) are not cached
+            return ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
+        key = (id(p), dtype16, transposed, pad_k)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+            return hit[2]
+        w = ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
+        self._c[key] = (p._version, p.data_ptr(), w)
+        return w
+
+    def clear(self):
+        self._c.clear()
+
+
+weights = _WeightCache()
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def _deliver(param, grad):
+    """Write a parameter gradient into its arena slot (if any) and tell autograd nothing is left to do."""
+    if param is None or not param.requires_grad:
+        return None
+    slot = getattr(param, "_vmc_grad", None)
+    if slot is None:
+        return grad.view(param.shape) if grad.shape != param.shape else grad
+    if grad.data_ptr() != slot.data_ptr():
+        slot.view(-1).copy_(grad.reshape(-1))      # device-to-device copy (plumbing); GEMMs write in place below
+    return None
+
+
+def _grad_out(param, shape):
+    """Destination for a parameter gradient: the arena slot when present (written in place)."""
+    slot = getattr(param, "_vmc_grad", None)
+    if slot is not None and tuple(slot.shape) == tuple(shape) and slot.is_contiguous():
+        return slot
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) (+ res).  x [M,Kx] 16-bit (Kx = K or K padded to 64), W [N,K...] f32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, act, out_f32):
+        dt16 = x.dtype
+        K = weight[0].numel()
+        w16 = weights.get(weight, dt16, pad_k=(K % 64 != 0))
+        if w16.shape[1] != x.shape[1]:
+            raise ValueError(f"LinearFn: x has {x.shape[1]} columns, weight needs {w16.shape[1]}")
+        b = bias.detach() if bias is not None else None
+        z = None
+        if act != ACT_NONE:
+            if res is not None:
+                raise ValueError("LinearFn: activation and residual are not combined on this path")
+            z = ops.linear(x, w16, bias=b)
+            y = ops.act_fwd(z, act)
+            if out_f32:
+                y = ops.cast32(y)
+        else:
+            y = ops.linear(x, w16, bias=b, res=res, out_dtype=torch.float32 if out_f32 else dt16)
+        ctx.save_for_backward(x, z)
+        ctx.weight, ctx.bias, ctx.act = weight, bias, act
+        ctx.has_res = res is not None
+        ctx.res_dtype = res.dtype if res is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z = ctx.saved_tensors
+        weight, bias, act = ctx.weight, ctx.bias, ctx.act
+        dt16 = x.dtype
+        M = x.shape[0]
+        N = weight.shape[0]
+        K = weight[0].numel()
+        dy = dy.contiguous()
+        dy16 = ops.cast16(dy, dt16)
+        dz = ops.act_bwd(z, dy16, act) if act != ACT_NONE else dy16
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy if dy.dtype == ctx.res_dtype else (ops.cast32(dy) if ctx.res_dtype == torch.float32 else dy16)
+        # ---- dgrad: dx = dz @ W  (contraction over N; pad N to a multiple of 64 with zeros) ----
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = weights.get(weight, dt16, transposed=True, pad_k=(N % 64 != 0))      # [K, Npad]
+            dzp = dz
+            if wt.shape[1] != N:
+                dzp = torch.zeros((M, wt.shape[1]), dtype=dt16, device=dz.device)
+                dzp[:, :N].copy_(dz)
+            dx = ops.linear(dzp, wt)                                                    # [M, K]
+            if x.shape[1] != K:                                                         # x was K-padded (patch GEMM)
+                pad = torch.zeros((M, x.shape[1]), dtype=dt16, device=dz.device)
+                pad[:, :K].copy_(dx)
+                dx = pad
+        # ---- wgrad: dW = dz^T @ x  (contraction over M; transposed operands, M zero-padded to 64) ----
+        dw = None
+        if weight.requires_grad:
+            Mp = _pad64(M)
+            dzt = torch.zeros((N, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((N, Mp), dtype=dt16, device=dz.device)
+            check(lib.vmc_transpose16(ptr(dz), ptr(dzt), M, N, dz.stride(0), Mp, stream()), "transpose16")
+            Kx = x.shape[1]
+            xt = torch.zeros((Kx, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((Kx, Mp), dtype=dt16, device=dz.device)
+            check(lib.vmc_transpose16(ptr(x), ptr(xt), M, Kx, x.stride(0), Mp, stream()), "transpose16")
+            if Kx == K and K % 4 == 0:
+                out = _grad_out(weight, (N, K))
+                ops.linear(dzt, xt, out=out.view(N, K))
+                dw = out
+            else:
+                full = ops.linear(dzt, xt, out_dtype=torch.float32)                    # [N, Kx]
+                dw = full[:, :K].contiguous()
+        db = None
+        if bias is not None and bias.requires_grad:
+            db = ops.colsum(dz)
+        return dx, _deliver(weight, dw), _deliver(bias, db), dres, None, None
+
+
+def linear(x, weight, bias=None, res=None, act=ACT_NONE, out_f32=False):
+    return LinearFn.apply(x, weight, bias, res, act, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (optionally forwarding its input so the residual fork is summed inside the backward kernel)
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, dt16, passthrough, out_f32):
+        D = gamma.shape[0]
+        rows = x.numel() // D
+        y16, y32, mean, rstd = ops.layernorm(x, gamma.detach(), beta.detach(), dt16, out16=not out_f32, out32=out_f32,
+                                             rows=rows, save_stats=True)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.dt16 = gamma, beta, dt16
+        y = y32 if out_f32 else y16
+        if passthrough:
+            return y, x.view(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dpass=None):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta, dt16 = ctx.gamma, ctx.beta, ctx.dt16
+        D = gamma.shape[0]
+        rows = x.numel() // D
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        add = None
+        if dpass is not None:
+            add = dpass.contiguous()
+            if add.dtype != x.dtype:
+                add = ops.cast32(add) if x.dtype == torch.float32 else ops.cast16(add, x.dtype)
+        dg = _grad_out(gamma, (D,))
+        db = _grad_out(beta, (D,))
+        nbytes = lib.vmc_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.vmc_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma.detach()), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dg), ptr(db),
+                                    rows, D, D, dt(dy), dt(x), dt(dx), dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
+        return dx, _deliver(gamma, dg), _deliver(beta, db), None, None, None
+
+
+def layernorm(x, gamma, beta, dt16, passthrough=False, out_f32=False):
+    return LayerNormFn.apply(x, gamma, beta, dt16, passthrough, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Attention
+# ------------------------------------------------------------------------------------------------
+def _attn_bwd(q, k, v, mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, dh, p=0.0, seed=0):
+    nbytes = lib.vmc_attention_bwd_workspace_bytes(B, H, Tq)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=q.device)
+    check(lib.vmc_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(mask), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
+                                B, H, Tq, Tk, dh, q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                dq.stride(0), dk.stride(0), dv.stride(0), float(p), int(seed), ptr(ws), nbytes, dt(q),
+                                stream()), "attention_bwd")
+
+
+class SelfAttnPackedFn(torch.autograd.Function):
+    """qkv [B*T, 3D] packed in_proj output -> o [B*T, D].  mask u8 [B,T] (1 = real token) or None."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, B, T, H):
+        D = qkv.shape[1] // 3
+        dh = D // H
+        if mask is None and dh == 64 and T <= 288:
+            out, lse = ops.attention_vit(qkv, B, T, H, want_lse=True)
+        else:
+            out, lse = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mask, B, H, T, T, dh, want_lse=True)
+        ctx.save_for_backward(qkv, out, lse, mask)
+        ctx.dims = (B, T, H, D, dh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, mask = ctx.saved_tensors
+        B, T, H, D, dh = ctx.dims
+        dout = ops.cast16(dout.contiguous(), qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        _attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], mask, out, dout, lse,
+                  dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, T, T, dh)
+        return dqkv, None, None, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """q [B*Tq, D], kv [B*Tk, 2D] (K | V) -> o [B*Tq, D]; mask u8 [B,Tk] over the keys."""
+
+    @staticmethod
+    def forward(ctx, q, kv, mask, B, Tq, Tk, H):
+        D = q.shape[1]
+        dh = D // H
+        out, lse = ops.attention(q, kv[:, :D], kv[:, D:], mask, B, H, Tq, Tk, dh, want_lse=True)
+        ctx.save_for_backward(q, kv, out, lse, mask)
+        ctx.dims = (B, Tq, Tk, H, D, dh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, mask = ctx.saved_tensors
+        B, Tq, Tk, H, D, dh = ctx.dims
+        dout = ops.cast16(dout.contiguous(), q.dtype)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _attn_bwd(q, kv[:, :D], kv[:, D:], mask, out, dout, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Tq, Tk, dh)
+        return dq, dkv, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# small pieces
+# ------------------------------------------------------------------------------------------------
+class CastFn(torch.autograd.Function):
+    """dtype change with the gradient cast back (f32 <-> 16-bit)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast32(x) if dtype == torch.float32 else ops.cast16(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return (ops.cast32(dy) if ctx.src == torch.float32 else ops.cast16(dy, ctx.src)), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+def _add(a, b, out_dtype, dt16):
+    y = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    check(lib.vmc_add(ptr(a), ptr(b), ptr(y), a.numel(), dt(a), dt(b), dt(y), dt(dt16), stream()), "add")
+    return y
+
+
+class ForkFn(torch.autograd.Function):
+    """x -> (x, x); the backward sums the two incoming gradients with vmc_add."""
+
+    @staticmethod
+    def forward(ctx, x, dt16):
+        ctx.dt16, ctx.dtype = dt16, x.dtype
+        return x.view(x.shape), x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        if d1 is None:
+            return d2, None
+        if d2 is None:
+            return d1, None
+        return _add(d1.contiguous(), d2.contiguous(), ctx.dtype, ctx.dt16), None
+
+
+def fork(x, dt16):
+    return ForkFn.apply(x, dt16)
+
+
+class AddFn(torch.autograd.Function):
+    """y = a + alpha * b (f32), ResidualMLP's skip (models/student_model.py:35)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = alpha
+        y = torch.empty_like(a)
+        check(lib.vmc_axpby_f32(ptr(a), ptr(b), ptr(y), a.numel(), 1.0, float(alpha), stream()), "axpby")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        db = torch.empty_like(dy)
+        check(lib.vmc_axpby_f32(ptr(dy), ptr(dy), ptr(db), dy.numel(), float(ctx.alpha), 0.0, stream()), "axpby")
+        return dy, db, None
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """[B*T, D] -> [B, D] mean over T (all rows, padded ones included: TFAM/models/AMO_CLIP.py:170)."""
+
+    @staticmethod
+    def forward(ctx, x, B, T, dt16, out_f32):
+        D = x.shape[-1]
+        o16, o32 = ops.mean_pool(x, B, T, D, dt16, out16=not out_f32, out32=out_f32)
+        ctx.meta = (B, T, D, x.dtype, dt16)
+        return o32 if out_f32 else o16
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D, xdtype, dt16 = ctx.meta
+        dout = dout.contiguous()
+        dx = torch.empty((B * T, D), dtype=xdtype, device=dout.device)
+        check(lib.vmc_mean_pool_bwd(ptr(dout), ptr(dx), B, T, D, dt(dout), dt(dx), dt(dt16), stream()), "mean_pool_bwd")
+        return dx, None, None, None, None
+
+
+class AssembleTokensFn(torch.autograd.Function):
+    """Patch rows + class token + positional embedding -> token matrix [F*N, D] (training path of K1)."""
+
+    @staticmethod
+    def forward(ctx, xp, cls, pos, F, N, out_dtype):
+        D = xp.shape[1]
+        x = torch.empty((F * N, D), dtype=out_dtype, device=xp.device)
+        check(lib.vmc_assemble_tokens(ptr(xp), ptr(cls.detach()), ptr(pos.detach()), ptr(x), F, N, D, dt(x), dt(xp), stream()),
+              "assemble_tokens")
+        ctx.cls, ctx.pos, ctx.meta = cls, pos, (F, N, D, xp.dtype)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        F, N, D, dt16 = ctx.meta
+        dx = dx.contiguous()
+        dpos = ops.colsum(dx.view(F, N * D)).view(N, D)                 # sum over frames
+        dcls = dpos[0].contiguous()
+        dxp = ops.cast16(dx.view(F, N, D)[:, 1:].contiguous().view(F * (N - 1), D), dt16)
+        return dxp, _deliver(ctx.cls, dcls), _deliver(ctx.pos, dpos), None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        y = torch.empty_like(x)
+        dt16 = x.dtype if x.dtype != torch.float32 else torch.bfloat16
+        check(lib.vmc_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed), dt(x), dt(dt16), stream()), "dropout")
+        ctx.meta = (p, seed, dt16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, dt16 = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.vmc_dropout(ptr(dy), ptr(dx), dy.numel(), float(p), int(seed), dt(dy), dt(dt16), stream()), "dropout")
+        return dx, None, None
+
+
+def dropout(x, p, training, seed_fn):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x.contiguous(), p, seed_fn())
+
+
+def scale_by_device_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
+    y = torch.empty_like(x)
+    s = scalar.reshape(1).float().contiguous()
+    check(lib.vmc_scale_by_device_scalar(ptr(x), ptr(y), x.numel(), ptr(s), stream()), "scale_by_device_scalar")
+    return y

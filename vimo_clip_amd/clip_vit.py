@@ -112,16 +112,12 @@ class VisionTransformer(nn.Module):
 
     # ---- 16-bit compute copies of the fp32 master weights -------------------------------------------
     def w16(self, name: str, param: torch.Tensor, transposed=False, pad_k=False) -> torch.Tensor:
-        key = (name, self.compute_dtype, transposed)
-        hit = self._w16.get(key)
-        if hit is not None and hit[0] == param._version and hit[1].device == param.device:
-            return hit[1]
-        w = ops.cast_weight(param, self.compute_dtype, transposed=transposed, pad_k=pad_k)
-        self._w16[key] = (param._version, w)
-        return w
+        from .autograd_ops import weights          # one cache for the inference and training paths
+        return weights.get(param, self.compute_dtype, transposed=transposed, pad_k=pad_k)
 
     def invalidate_weight_cache(self):
-        self._w16.clear()
+        from .autograd_ops import weights
+        weights.clear()
 
     # ---- inference forward ---------------------------------------------------------------------------
     @torch.no_grad()

@@ -183,7 +183,8 @@ template <typename T>
 __global__ void __launch_bounds__(64) attn_generic_fwd(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                        const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
                                                        uint16_t* __restrict__ op, float* __restrict__ lse, int H, int Tq,
-                                                       int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale) {
+                                                       int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                                       float drop_p, unsigned long long seed) {
   __shared__ float qs[ATT_MAX_DH];
   __shared__ float ps[ATT_MAX_TK];
   const int lane = threadIdx.x;
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(64) attn_generic_fwd(const uint16_t* __restric
   float sum = 0.f;
   for (int key = lane; key < Tk; key += 64) {
     const float p = __expf(ps[key] - m);  // all-masked row: (-inf) - (-inf) = NaN, as torch
-    ps[key] = p;
+    // dropout acts on the normalised probabilities (nn.MultiheadAttention(dropout=p)); the row sum does not see it
+    ps[key] = p * dropout_factor(drop_p, seed, (((size_t)b * H + h) * Tq + t) * Tk + key);
     sum += p;
   }
   sum = wave_sum(sum);
@@ -224,7 +226,8 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_q(const uint16_t* __restr
                                                          const uint16_t* __restrict__ op, const uint16_t* __restrict__ dop,
                                                          const float* __restrict__ lse, uint16_t* __restrict__ dqp,
                                                          float* __restrict__ delta, int H, int Tq, int Tk, int dh, int ldq,
-                                                         int ldk, int ldv, int ldo, int lddq, float scale) {
+                                                         int ldk, int ldv, int ldo, int lddq, float scale, float drop_p,
+                                                         unsigned long long seed) {
   __shared__ float qs[ATT_MAX_DH];
   __shared__ float dos[ATT_MAX_DH];
   __shared__ float ds[ATT_MAX_TK];
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_q(const uint16_t* __restr
       const size_t ki = (size_t)b * Tk + key;
       const float p = __expf(dot16<T>(kp + ki * ldk + h * dh, qs, dh) - l);
       const float dp = dot16<T>(vp + ki * ldv + h * dh, dos, dh);
-      dsv = p * (dp - dl);
+      dsv = p * (dp * dropout_factor(drop_p, seed, (((size_t)b * H + h) * Tq + t) * Tk + key) - dl);
     }
     ds[key] = dsv;
   }
@@ -268,7 +271,8 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __rest
                                                           const uint16_t* __restrict__ dop, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, uint16_t* __restrict__ dkp,
                                                           uint16_t* __restrict__ dvp, int H, int Tq, int Tk, int dh, int ldq,
-                                                          int ldk, int ldv, int ldo, int lddk, int lddv, float scale) {
+                                                          int ldk, int ldv, int ldo, int lddk, int lddv, float scale,
+                                                          float drop_p, unsigned long long seed) {
   __shared__ float ks[ATT_MAX_DH];
   __shared__ float vs[ATT_MAX_DH];
   __shared__ float pbuf[ATT_MAX_TK];   // p[t]  for this key
@@ -289,7 +293,9 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __rest
       const size_t si = ((size_t)b * H + h) * Tq + t;
       p = __expf(dot16<T>(qp + qi * ldq + h * dh, ks, dh) * scale - lse[si]);
       const float dp = dot16<T>(dop + qi * ldo + h * dh, vs, dh);
-      dsv = p * (dp - delta[si]);
+      const float dfac = dropout_factor(drop_p, seed, (((size_t)b * H + h) * Tq + t) * Tk + key);
+      dsv = p * (dp * dfac - delta[si]);
+      p *= dfac;  // dV sees the dropped probabilities
     }
     pbuf[t] = p;
     dsbuf[t] = dsv;
@@ -316,8 +322,8 @@ static int check_generic(int B, int H, int Tq, int Tk, int dh, int ldq, int ldk,
 
 extern "C" int vmc_attention_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* out,
                                  float* lse, int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo,
-                                 int dtype16, void* stream) {
-  if (!q || !k || !v || !out) return VMC_E_ARG;
+                                 float dropout_p, uint64_t dropout_seed, int dtype16, void* stream) {
+  if (!q || !k || !v || !out || dropout_p < 0.f || dropout_p >= 1.f) return VMC_E_ARG;
   int rc = check_generic(B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo);
   if (rc) return rc;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return VMC_E_ALIGN;
@@ -325,10 +331,12 @@ extern "C" int vmc_attention_fwd(const void* q, const void* k, const void* v, co
   dim3 grid(B * H * Tq);
   if (dtype16 == VMC_BF16)
     hipLaunchKernelGGL(attn_generic_fwd<BF16>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale);
+                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, dropout_p,
+                       (unsigned long long)dropout_seed);
   else if (dtype16 == VMC_F16)
     hipLaunchKernelGGL(attn_generic_fwd<F16>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale);
+                       (const uint16_t*)v, key_mask, (uint16_t*)out, lse, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, dropout_p,
+                       (unsigned long long)dropout_seed);
   else
     return VMC_E_DTYPE;
   VMC_CHECK_LAUNCH();
@@ -340,7 +348,8 @@ extern "C" size_t vmc_attention_bwd_workspace_bytes(int B, int H, int Tq) { retu
 extern "C" int vmc_attention_bwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, const void* out,
                                  const void* dout, const float* lse, void* dq, void* dk, void* dv, int B, int H, int Tq,
                                  int Tk, int dh, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                                 void* workspace, size_t workspace_bytes, int dtype16, void* stream) {
+                                 float dropout_p, uint64_t dropout_seed, void* workspace, size_t workspace_bytes, int dtype16,
+                                 void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return VMC_E_ARG;
   int rc = check_generic(B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo);
   if (rc) return rc;
@@ -352,10 +361,10 @@ extern "C" int vmc_attention_bwd(const void* q, const void* k, const void* v, co
 #define VMC_LAUNCH_BWD(TT)                                                                                                   \
   hipLaunchKernelGGL(attn_generic_bwd_q<TT>, dim3(B * H * Tq), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,       \
                      (const uint16_t*)v, key_mask, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dq, delta, H, \
-                     Tq, Tk, dh, ldq, ldk, ldv, ldo, lddq, scale);                                                            \
+                     Tq, Tk, dh, ldq, ldk, ldv, ldo, lddq, scale, dropout_p, (unsigned long long)dropout_seed);                                                            \
   hipLaunchKernelGGL(attn_generic_bwd_kv<TT>, dim3(B * H * Tk), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,      \
                      (const uint16_t*)v, key_mask, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, H, Tq, Tk, \
-                     dh, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+                     dh, ldq, ldk, ldv, ldo, lddk, lddv, scale, dropout_p, (unsigned long long)dropout_seed);
   if (dtype16 == VMC_BF16) {
     VMC_LAUNCH_BWD(BF16)
   } else if (dtype16 == VMC_F16) {

@@ -96,6 +96,19 @@ __device__ inline float act_grad_rt(float x, int act) {
   }
 }
 
+// Counter-based keep mask for dropout: element i of stream `seed` is kept iff hash32 >= p * 2^32.
+__device__ inline uint32_t hash32(uint64_t seed, uint64_t i) {
+  uint64_t x = (i + 0x9E3779B97F4A7C15ull) ^ seed;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+__device__ inline float dropout_factor(float p, uint64_t seed, uint64_t i) {
+  if (p <= 0.f) return 1.0f;
+  return hash32(seed, i) >= (uint32_t)((double)p * 4294967296.0) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 static inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)max_blocks) g = max_blocks;

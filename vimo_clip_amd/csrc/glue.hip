@@ -1,0 +1,92 @@
+// Small training-path kernels: gradient fork sums, mean-pool backward, token assembly, dropout (gfx950).
+#include "common.h"
+
+template <typename T>
+__device__ inline float ld1(const void* p, size_t i, bool f32) {
+  return f32 ? ((const float*)p)[i] : T::to_f32(((const uint16_t*)p)[i]);
+}
+template <typename T>
+__device__ inline void st1(void* p, size_t i, bool f32, float v) {
+  if (f32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = T::from_f32(v);
+}
+
+#define VMC_DISPATCH16(KERNEL, GRID, ...)                                                                      \
+  if (dtype16 == VMC_F16) hipLaunchKernelGGL(KERNEL<F16>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+  else if (dtype16 == VMC_BF16) hipLaunchKernelGGL(KERNEL<BF16>, dim3(GRID), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+  else return VMC_E_DTYPE;                                                                                     \
+  VMC_CHECK_LAUNCH();                                                                                          \
+  return 0;
+
+// y = a + b  (sum of the two gradients that meet at a fork), any mix of f32 / 16-bit
+template <typename T>
+__global__ void add_kernel(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ y, size_t n, int a_f32, int b_f32,
+                           int y_f32) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    st1<T>(y, i, y_f32, ld1<T>(a, i, a_f32) + ld1<T>(b, i, b_f32));
+}
+extern "C" int vmc_add(const void* a, const void* b, void* y, size_t n, int a_dtype, int b_dtype, int y_dtype, int dtype16, void* stream) {
+  if (!a || !b || !y || n == 0) return VMC_E_ARG;
+  VMC_DISPATCH16(add_kernel, grid_for(n, 256), a, b, y, n, a_dtype == VMC_F32, b_dtype == VMC_F32, y_dtype == VMC_F32)
+}
+
+// dx[b,t,:] = dout[b,:] / T   (backward of vmc_mean_pool)
+template <typename T>
+__global__ void mean_pool_bwd_kernel(const void* __restrict__ dout, void* __restrict__ dx, int B, int Tn, int D, int do_f32, int dx_f32) {
+  const size_t total = (size_t)B * Tn * D;
+  const float inv = 1.0f / (float)Tn;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)Tn * D);
+    const int d = (int)(i % D);
+    st1<T>(dx, i, dx_f32, ld1<T>(dout, b * D + d, do_f32) * inv);
+  }
+}
+extern "C" int vmc_mean_pool_bwd(const void* dout, void* dx, int B, int Tn, int D, int dout_dtype, int dx_dtype, int dtype16, void* stream) {
+  if (!dout || !dx || B <= 0 || Tn <= 0 || D <= 0) return VMC_E_ARG;
+  VMC_DISPATCH16(mean_pool_bwd_kernel, grid_for((size_t)B * Tn * D, 256), dout, dx, B, Tn, D, dout_dtype == VMC_F32, dx_dtype == VMC_F32)
+}
+
+// Token assembly (training path of K1): x[f,0,:] = cls + pos[0];  x[f,1+p,:] = xp[f*g2+p,:] + pos[1+p]
+template <typename T>
+__global__ void assemble_tokens_kernel(const uint16_t* __restrict__ xp, const float* __restrict__ cls, const float* __restrict__ pos,
+                                       void* __restrict__ x, int F, int N, int D, int x_f32) {
+  const size_t total = (size_t)F * N * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int n = (int)((i / D) % N);
+    const size_t f = i / ((size_t)N * D);
+    const float v = (n == 0 ? cls[d] : T::to_f32(xp[(f * (N - 1) + (n - 1)) * D + d])) + pos[(size_t)n * D + d];
+    st1<T>(x, i, x_f32, v);
+  }
+}
+extern "C" int vmc_assemble_tokens(const void* xp, const float* cls, const float* pos, void* x, int F, int N, int D, int x_dtype,
+                                   int dtype16, void* stream) {
+  if (!xp || !cls || !pos || !x || F <= 0 || N <= 1 || D <= 0) return VMC_E_ARG;
+  VMC_DISPATCH16(assemble_tokens_kernel, grid_for((size_t)F * N * D, 256), (const uint16_t*)xp, cls, pos, x, F, N, D, x_dtype == VMC_F32)
+}
+
+// Inverted dropout with a counter-based keep mask: keep(i) = hash(seed, i) >= p; y = x * keep / (1 - p).
+// The backward calls the same function on dy with the same (seed, p): no mask is stored.
+template <typename T>
+__global__ void dropout_kernel(const void* __restrict__ x, void* __restrict__ y, size_t n, float p, uint64_t seed, int f32) {
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  const float sc = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    st1<T>(y, i, f32, hash32(seed, i) >= thr ? ld1<T>(x, i, f32) * sc : 0.0f);
+}
+extern "C" int vmc_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int x_dtype, int dtype16, void* stream) {
+  if (!x || !y || n == 0 || p < 0.f || p >= 1.f) return VMC_E_ARG;
+  VMC_DISPATCH16(dropout_kernel, grid_for(n, 256), x, y, n, p, seed, x_dtype == VMC_F32)
+}
+
+// y = x * (*scale)   with the scale read from device memory (incoming scalar gradient of a loss)
+__global__ void scale_dev_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, const float* __restrict__ scale) {
+  const float s = scale[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+extern "C" int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, const float* scale, void* stream) {
+  if (!x || !y || !scale || n == 0) return VMC_E_ARG;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, scale);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}

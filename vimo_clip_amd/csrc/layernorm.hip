@@ -104,8 +104,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows, int D, size_t ldx, int dy_f32,
-                                                     int x_f32, int dx_f32) {
+                                                     const void* __restrict__ addp, float* __restrict__ partial, int rows,
+                                                     int D, size_t ldx, int dy_f32, int x_f32, int dx_f32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][2][D] floats
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
@@ -144,6 +144,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
         o.y = rs * (g[c].y - s1 - xh[c].y * s2);
         o.z = rs * (g[c].z - s1 - xh[c].z * s2);
         o.w = rs * (g[c].w - s1 - xh[c].w * s2);
+        if (addp) {  // fused residual-branch gradient: dx = LN'(dy) + add   (add has dx's dtype and layout)
+          const float4 ad = load4<T>(addp, (size_t)row * D + col, dx_f32);
+          o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+        }
         store4<T>(dx, (size_t)row * D + col, dx_f32, o);
       }
     }
@@ -185,8 +189,8 @@ extern "C" size_t vmc_layernorm_bwd_workspace_bytes(int rows, int D) {
 }
 
 extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype, int x_dtype,
-                                 int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
+                                 const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                                 int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return VMC_E_ARG;
   if (D % 4 || D > LN_BWD_MAX_CHUNKS * 256) return VMC_E_SHAPE;
   if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
@@ -195,11 +199,11 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
   const size_t lds = (size_t)8 * D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype16 == VMC_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<BF16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, (float*)workspace, rows,
-                       D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
+    hipLaunchKernelGGL(ln_bwd_kernel<BF16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add, (float*)workspace,
+                       rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
   else if (dtype16 == VMC_F16)
-    hipLaunchKernelGGL(ln_bwd_kernel<F16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, (float*)workspace, rows, D,
-                       (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
+    hipLaunchKernelGGL(ln_bwd_kernel<F16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add, (float*)workspace,
+                       rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
   else
     return VMC_E_DTYPE;
   VMC_CHECK_LAUNCH();

@@ -1,0 +1,89 @@
+"""Teacher embedding extraction — the accelerated slice of the reference's extract_embeddings.py.
+
+``sample_frame_indices`` (:77-81), ``frames_to_nchw`` (:84), ``multi_hot`` (:97-103) and ``encode_video_frames``
+(:89-94: per-frame PIL + CLIPImageProcessor + ``get_image_features`` -> one fused HIP pass) are the pieces on
+the hot path; ``create_hdf5_dataset`` keeps the reference's signature and file layout and needs decord + h5py
+(absent offline; imported lazily so their absence is loud).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+
+def sample_frame_indices(total_frames: int, max_frames=None) -> np.ndarray:
+    """extract_embeddings.py:77-81, bit-exact."""
+    if (max_frames is None) or (total_frames <= max_frames):
+        return np.arange(total_frames)
+    step = total_frames // max_frames
+    return np.arange(0, total_frames, step)[:max_frames]
+
+
+def frames_to_nchw(frames_nhwc: torch.Tensor) -> torch.Tensor:
+    """decord ``get_batch`` gives [T,H,W,3] u8; the reference permutes to [T,3,H,W] (:84)."""
+    return frames_nhwc.permute(0, 3, 1, 2)
+
+
+def multi_hot(labels, num_classes: int) -> np.ndarray:
+    """:97-103 (labels outside [0, num_classes) are skipped with a warning in the reference)."""
+    out = np.zeros(num_classes, dtype=np.float32)
+    for lab in labels:
+        if 0 <= int(lab) < num_classes:
+            out[int(lab)] = 1.0
+    return out
+
+
+@torch.no_grad()
+def encode_video_frames(encoder, frames_u8_nchw: torch.Tensor) -> np.ndarray:
+    """[T,3,R,R] u8 (already at the model resolution) -> [T,E] float32 numpy, like
+    ``clip_model.get_image_features(pixel_values).cpu().numpy()`` (:94)."""
+    vis = getattr(encoder, "visual", encoder)
+    dev = next(vis.parameters()).device
+    return vis.encode_frames_u8(frames_u8_nchw.to(dev)).cpu().numpy()
+
+
+def create_hdf5_dataset(data_root, annotation_file, class_file, output_hdf5, max_frames=None, encoder=None,
+                        clip_model_name="ViT-B/16"):
+    """Reference signature (:23) + an optional prebuilt encoder.  Output layout (:106-119): group per video with
+    ``embeddings`` [T,E] f32 gzip chunks (1,E), ``labels`` [C] f32, attrs total_frames/original_frames; root attrs
+    and a ``video_ids`` dataset."""
+    import decord  # noqa: F401
+    import h5py
+    import pandas as pd
+    from decord import VideoReader, cpu
+
+    from .clip_vit import CLIPImageEncoder
+    decord.bridge.set_bridge("torch")
+    encoder = encoder or CLIPImageEncoder(clip_model_name).cuda().eval()
+    out_dir = os.path.dirname(output_hdf5)
+    if out_dir and not os.path.exists(out_dir):
+        os.makedirs(out_dir)
+    num_classes = len(pd.read_csv(class_file))
+    with open(annotation_file, "r", encoding="utf-8") as f:
+        annotations = [line.strip().split() for line in f if line.strip()]
+    with h5py.File(output_hdf5, "w") as hf:
+        hf.attrs["num_classes"], hf.attrs["dataset_name"], hf.attrs["type"], hf.attrs["clip_model"] = num_classes, "AnimalKingdom", "val", clip_model_name
+        for info in annotations:
+            video_id, video_path = info[0], os.path.join(data_root, info[0])
+            if not os.path.exists(video_path):
+                print(f"Video no encontrado: {video_path}")
+                continue
+            try:
+                vr = VideoReader(video_path, ctx=cpu(0))
+                total = len(vr)
+                idx = sample_frame_indices(total, max_frames)
+                frames = frames_to_nchw(vr.get_batch(idx))
+                R = encoder.visual.input_resolution
+                if tuple(frames.shape[-2:]) != (R, R):
+                    raise NotImplementedError("PIL-exact resize/crop on the GPU is SURVEY.md §8f item 1")
+                emb = encode_video_frames(encoder, frames)
+                grp = hf.create_group(video_id)
+                grp.create_dataset("embeddings", data=emb, compression="gzip", chunks=(1, emb.shape[1]))
+                grp.create_dataset("labels", data=multi_hot([int(x) for x in info[1:]], num_classes))
+                grp.attrs["total_frames"], grp.attrs["original_frames"] = len(idx), total
+            except Exception as e:  # the reference logs and continues (:113-115)
+                print(f"\nError procesando {video_id}: {str(e)}")
+                continue
+        hf.create_dataset("video_ids", data=np.array([a[0] for a in annotations], dtype=h5py.string_dtype()))

@@ -97,12 +97,13 @@ def attention_vit(qkv: torch.Tensor, F: int, N: int, H: int, want_lse: bool = Fa
     return out, lse
 
 
-def attention(q, k, v, key_mask_u8, B, H, Tq, Tk, dh, want_lse=False):
+def attention(q, k, v, key_mask_u8, B, H, Tq, Tk, dh, want_lse=False, dropout_p=0.0, dropout_seed=0):
     """Generic masked attention.  q/k/v are 2-D 16-bit views [B*T, ld] whose first H*dh columns are used."""
     out = torch.empty((B * Tq, H * dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if want_lse else None
     check(lib.vmc_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask_u8), ptr(out), ptr(lse), B, H, Tq, Tk, dh,
-                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), dt(q), stream()), "attention_fwd")
+                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(dropout_p), int(dropout_seed),
+                                dt(q), stream()), "attention_fwd")
     return out, lse
 
 

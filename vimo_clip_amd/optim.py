@@ -1,0 +1,120 @@
+"""Flat parameter/gradient arena, fused Adam/AdamW (K15) and the reference's LR schedule.
+
+``GradArena`` lays the parameters that receive gradients out in ONE flat fp32 buffer (plus a flat
+gradient buffer, Adam m and v): every ``p.data`` / ``p.grad`` becomes a 64-element-aligned view, the
+backward kernels write gradients in place (autograd_ops._grad_out), the optimiser is one vmc_adam_step
+launch over the whole arena (28 B/parameter of HBM traffic), and data-parallel training all-reduces the
+flat gradient buffer in large buckets (parallel.py).  Mirrors ``torch.optim.Adam(lr)`` (train.py:66) and
+``torch.optim.AdamW(lr=1e-4, weight_decay=0.1)`` + ``CosineAnnealingLR(T_max=epochs, eta_min=1e-6)``
+(TFAM/train_and_eval.py:53-56) in arithmetic.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+_ALIGN = 64
+
+
+class GradArena:
+    def __init__(self, params):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("GradArena: no trainable parameters")
+        dev = params[0].device
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(params, self.offsets):
+            n = p.numel()
+            self.flat_param[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[o:o + n].view(p.shape)
+            g = self.flat_grad[o:o + n].view(p.shape)
+            p.grad = g
+            p._vmc_grad = g
+
+    def zero_grad(self):
+        """Not needed between steps (every used gradient is overwritten by its backward kernel); provided
+        for loops that call it anyway."""
+        self.flat_grad.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        out = torch.zeros(1, dtype=torch.float32, device=self.flat_grad.device)
+        check(lib.vmc_sumsq(ptr(self.flat_grad), self.numel, ptr(out), stream()), "sumsq")
+        return out.sqrt()
+
+    def buckets(self, bucket_bytes: int = 48 << 20):
+        """Contiguous views of the flat gradient buffer of at most ``bucket_bytes`` each (all-reduce units)."""
+        n = max(_ALIGN, bucket_bytes // 4 // _ALIGN * _ALIGN)
+        return [self.flat_grad[s:min(self.numel, s + n)] for s in range(0, self.numel, n)]
+
+
+class FusedAdam:
+    """Adam / AdamW over a GradArena: one kernel launch per step."""
+
+    def __init__(self, arena: GradArena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        self.arena = arena
+        self.lr, self.betas, self.eps, self.weight_decay, self.decoupled = lr, betas, eps, weight_decay, decoupled
+        self.m = torch.zeros_like(arena.flat_param)
+        self.v = torch.zeros_like(arena.flat_param)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr}]          # what LR schedulers / loggers poke at
+
+    def zero_grad(self, set_to_none: bool = False):
+        pass                                       # gradients are overwritten in place every backward
+
+    def step(self, grad_scale: float = 1.0, max_grad_norm=None):
+        a = self.arena
+        if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
+            total = float(a.grad_norm().item())
+            grad_scale = grad_scale * min(1.0, max_grad_norm / (total + 1e-6))
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        check(lib.vmc_adam_step(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, float(lr),
+                                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                int(self.decoupled), self.step_count, float(grad_scale), stream()), "adam_step")
+        invalidate_weight_copies()
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.param_groups[0]["lr"] = sd["lr"]
+
+
+def invalidate_weight_copies():
+    """The optimiser kernel wrote the fp32 masters behind autograd's version counters: drop the cached
+    16-bit compute copies so the next forward re-casts them."""
+    from . import autograd_ops
+    autograd_ops.weights.clear()
+
+
+class CosineAnnealingLR:
+    """Closed form of torch's CosineAnnealingLR(T_max, eta_min), stepped once per epoch (train_and_eval.py:162)."""
+
+    def __init__(self, optimizer, T_max, eta_min=0.0):
+        self.opt, self.T_max, self.eta_min = optimizer, T_max, eta_min
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.param_groups[0]["lr"] = self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lr": self.base_lr}

@@ -1,0 +1,100 @@
+"""Clip-level data parallelism: one process per GPU, gradients all-reduced over RCCL/xGMI.
+
+Replaces the reference's single-process ``torch.nn.DataParallel`` (train.py:64, TFAM/train_and_eval.py:392:
+per-step parameter broadcast + input scatter + output gather + reduce_add of gradients onto GPU 0) by the
+one exchange the algorithm needs: a SUM all-reduce of the flat gradient arena per step, in ~48 MB buckets
+issued asynchronously (each bucket is a contiguous slice of GradArena.flat_grad; NCCL == RCCL on ROCm), the
+mean folded into the optimiser's ``grad_scale``.  Parameters that get no gradient in the active fusion mode
+are not in the arena, so nothing is reduced for them (SURVEY.md §7 "DDP with unused parameters").
+
+Works with the ``gloo`` backend on CPU tensors too (tests/test_parallel_cpu.py, world_size 2).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_range(n_items: int, rank: int, world: int, drop_last: bool = True):
+    """Contiguous shard of ``n_items`` clips for ``rank`` (DistributedSampler-style, drop_last mirrors the
+    reference loaders, TFAM/train_and_eval.py:374,398)."""
+    if drop_last:
+        per = n_items // world
+        return rank * per, (rank + 1) * per
+    per = (n_items + world - 1) // world
+    return min(n_items, rank * per), min(n_items, (rank + 1) * per)
+
+
+class GradientAllReducer:
+    """Bucketed asynchronous SUM all-reduce of a flat gradient buffer."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 48 << 20):
+        self.flat = flat_grad
+        n = max(64, bucket_bytes // flat_grad.element_size())
+        self.buckets = [flat_grad[s:min(flat_grad.numel(), s + n)] for s in range(0, flat_grad.numel(), n)]
+        self._pending = []
+
+    def start(self):
+        if world_size() == 1:
+            return
+        self._pending = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+
+    def finish(self) -> float:
+        """Wait for the buckets; returns the factor the optimiser must scale gradients by (1/world)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        return 1.0 / world_size()
+
+    def all_reduce(self) -> float:
+        self.start()
+        return self.finish()
+
+
+def broadcast_parameters(flat_param: torch.Tensor, src: int = 0):
+    """Make every replica start from rank ``src``'s weights (one broadcast of the flat arena)."""
+    if world_size() > 1:
+        dist.broadcast(flat_param, src=src)
+
+
+def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """Concatenate per-rank [n_local, C] score/target matrices (exact micro-AP needs all of them: a mean of
+    per-rank APs is not the global AP)."""
+    if world_size() == 1:
+        return x
+    counts = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world_size())]
+    dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    nmax = int(max(c.item() for c in counts))
+    pad = torch.zeros((nmax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    outs = [torch.empty_like(pad) for _ in range(world_size())]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: int(c.item())] for o, c in zip(outs, counts)], dim=0)
+
+
+def all_reduce_scalars(values: torch.Tensor) -> torch.Tensor:
+    if world_size() > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+    return values
