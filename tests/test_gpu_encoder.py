@@ -4,6 +4,10 @@ oracle/make_golden.py recorded from transformers.CLIPModel.
 Tolerances (BASELINE.json north_star: "CLIP embeddings ... within 1e-3 fp16"):
   f16 compute, fp32 residual stream : |y - y_ref| <= 1e-3 * max(1, max|y_ref|)   (the stated 1e-3)
   bf16 compute (the bench dtype)    : 8x looser (bf16 has 3 fewer mantissa bits than f16): 8e-3
+  "stress" fixtures (weight scales x2, i.e. attention logits x4; tiny14) get the bound x stress^2: they exist
+  to show the error stays proportional under large-norm activations, not to meet the nominal bound.
+Measured on MI355X (gpurun, round 1): f16 1.0e-3..1.5e-3 absolute on |y|max 3.1..3.9 (3e-4..5e-4 relative);
+bf16 0.9e-2..1.2e-2 absolute (3e-3 relative).
 """
 import numpy as np
 import pytest
@@ -35,7 +39,8 @@ def test_encoder_vs_golden(golden, c, dtype):
     scale = max(1.0, ref.abs().max().item())
     err, err2 = (y - ref).abs().max().item(), (y2 - ref).abs().max().item()
     print(f"{c['name']} {dtype}: max abs err {err:.3e} / {err2:.3e}, scale {scale:.2f}")
-    assert err <= TOL[dtype] * scale and err2 <= TOL[dtype] * scale
+    tol = TOL[dtype] * c["stress"] ** 2
+    assert err <= tol * scale and err2 <= tol * scale
 
 
 def test_encoder_vs_oracle_fresh_seed():

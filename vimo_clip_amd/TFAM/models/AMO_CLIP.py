@@ -26,8 +26,6 @@ from ... import autograd_ops as ag
 from ... import ops
 from ...clip_vit import _Lin, _LN
 
-_seed_counter = itertools.count(1)
-
 
 class _MHA(nn.Module):
     """Parameter holder with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
@@ -203,14 +201,15 @@ class AMO_CLIP(nn.Module):
         self.classifier = nn.Sequential(_LN(d_model), _linear_init(_Lin(d_model, d_model // 2)), _Slot(), _Slot(),
                                         _linear_init(_Lin(d_model // 2, num_classes)))
         self.projection_layer = _linear_init(_Lin(2 * d_model, d_model))
-        self._seed_base = 0x5EED
+        self.set_dropout_seed(0x5EED)
 
     def set_dropout_seed(self, seed: int):
-        """Per-rank / per-run base seed of the counter-based dropout masks."""
+        """Per-rank / per-run base seed of the counter-based dropout masks; restarts the mask sequence."""
         self._seed_base = int(seed)
+        self._seed_iter = itertools.count(1)
 
     def _next_seed(self):
-        return (self._seed_base << 20) ^ next(_seed_counter)
+        return ((self._seed_base << 24) ^ next(self._seed_iter)) & 0xFFFFFFFFFFFFFFFF
 
     def positional_encoding(self, seq_len):
         """Sinusoidal table [seq_len, d_model] (:88-97), produced by the same kernel that adds it."""

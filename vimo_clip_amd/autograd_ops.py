@@ -12,6 +12,8 @@ function says otherwise; parameters are fp32 masters whose 16-bit copies are cac
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -32,10 +34,11 @@ class _WeightCache:
             return ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
         key = (id(p), dtype16, transposed, pad_k)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
-            return hit[2]
+        # id() values are recycled once a parameter dies: the weak reference proves it is still the same object
+        if hit is not None and hit[0]() is p and hit[1] == p._version and hit[2] == p.data_ptr():
+            return hit[3]
         w = ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
-        self._c[key] = (p._version, p.data_ptr(), w)
+        self._c[key] = (weakref.ref(p), p._version, p.data_ptr(), w)
         return w
 
     def clear(self):
@@ -80,8 +83,13 @@ class LinearFn(torch.autograd.Function):
         dt16 = x.dtype
         K = weight[0].numel()
         w16 = weights.get(weight, dt16, pad_k=(K % 64 != 0))
+        ctx.x_cols = x.shape[1]
         if w16.shape[1] != x.shape[1]:
-            raise ValueError(f"LinearFn: x has {x.shape[1]} columns, weight needs {w16.shape[1]}")
+            if x.shape[1] != K:
+                raise ValueError(f"LinearFn: x has {x.shape[1]} columns, weight needs {K} (or {w16.shape[1]} padded)")
+            xp = torch.zeros((x.shape[0], w16.shape[1]), dtype=dt16, device=x.device)   # K not a multiple of 64: zero-pad
+            xp[:, :K].copy_(x)
+            x = xp
         b = bias.detach() if bias is not None else None
         z = None
         if act != ACT_NONE:
@@ -122,7 +130,7 @@ class LinearFn(torch.autograd.Function):
                 dzp = torch.zeros((M, wt.shape[1]), dtype=dt16, device=dz.device)
                 dzp[:, :N].copy_(dz)
             dx = ops.linear(dzp, wt)                                                    # [M, K]
-            if x.shape[1] != K:                                                         # x was K-padded (patch GEMM)
+            if ctx.x_cols != K:                                                         # caller passed K-padded x (patch GEMM)
                 pad = torch.zeros((M, x.shape[1]), dtype=dt16, device=dz.device)
                 pad[:, :K].copy_(dx)
                 dx = pad
