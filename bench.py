@@ -38,6 +38,85 @@ def vit_flops_per_frame(name: str) -> float:
     return 2 * (N - 1) * 3 * p * p * D + L * (6 * N * D * D + 4 * N * N * D + 2 * N * D * D + 4 * N * D * M) + 2 * D * E
 
 
+def _time_cuda(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def tfam_extras(dev, rank, world, cdt):
+    """TFAM (BASELINE.json configs[3]): d_model 768, 8 heads, 4 layers, ff 2048, 16x768 RGB + motion tokens,
+    cross-attention.  Forward clips/s at small and large batch; full train step (fwd + bwd + gradient all-reduce
+    over RCCL when world > 1 + fused AdamW) with the HBM roofline of the AdamW kernel (28 B/parameter)."""
+    import torch.distributed as dist
+
+    from vimo_clip_amd import synth
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    from vimo_clip_amd.parallel import GradientAllReducer, broadcast_parameters
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+
+    out = {}
+    m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0,
+                 device=dev, compute_dtype=cdt).to(dev)
+    m.load_state_dict(synth.tfam_state_dict(768, 8, 4, 2048, 140, 4), strict=True)
+    flops_clip = 1.0136e9
+    for B in (8, 512, 4096):
+        rgb = synth.normal(10 + rank, f"rgb{B}", (B, 16, 768)).to(dev)
+        mot = synth.normal(10 + rank, f"mot{B}", (B, 16, 768)).to(dev)
+        mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
+        m.eval()
+        with torch.no_grad():
+            t = _time_cuda(lambda: m(rgb, mot, mask_rgb=mk, mask_flow=mk), 20 if B <= 512 else 5)
+        out[f"tfam_fwd_clips_per_s_B{B}"] = round(B / t, 1)
+        out[f"tfam_fwd_mfma_frac_B{B}"] = round(B / t * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)
+    # ---- train step, per-GPU batch 512 (weak scaling), AdamW lr 1e-4 wd 0.1 as TFAM/train_and_eval.py:53 ----
+    B = 512
+    m.train()
+    arena = GradArena(m.used_parameters())
+    broadcast_parameters(arena.flat_param)
+    opt = FusedAdam(arena, lr=1e-4, weight_decay=0.1, decoupled=True)
+    red = GradientAllReducer(arena.flat_grad)
+    rgb = synth.normal(20 + rank, "rgb_t", (B, 16, 768)).to(dev)
+    mot = synth.normal(20 + rank, "mot_t", (B, 16, 768)).to(dev)
+    mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
+    y = synth.multi_hot_labels(20 + rank, "lab_t", B, 140).to(dev)
+
+    def train_step():
+        loss = bce_with_logits_loss(m(rgb, mot, mask_rgb=mk, mask_flow=mk), y)
+        loss.backward()
+        opt.step(grad_scale=red.all_reduce())
+
+    t = _time_cuda(train_step, 10)
+    if world > 1:
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    out["tfam_train_clips_per_s_B512_per_gpu"] = round(B * world / t, 1)
+    out["tfam_train_ms_per_step"] = round(1e3 * t, 3)
+    out["tfam_grad_allreduce_bytes"] = arena.numel * 4
+    # AdamW kernel alone: HIP events on the launch stream, HBM roofline (16 B read + 12 B write per parameter)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    opt.step()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        opt.step()
+    e1.record()
+    torch.cuda.synchronize()
+    t_adam = e0.elapsed_time(e1) * 1e-3 / 20
+    bytes_adam = arena.numel * 28.0
+    out["adamw_roofline"] = {"bound": "hbm", "achieved": round(bytes_adam / t_adam / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(bytes_adam / t_adam / 8e12, 4), "params": arena.numel,
+                             "note": "133 MB of state fits the 256 MiB Infinity Cache: MALL-resident, not an HBM-only figure"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +127,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the TFAM measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,6 +189,9 @@ def main():
         "per_gpu_value": round(fps / world, 2),
         "end_to_end_mfma_frac": round(fps / world * flops_frame / (MFMA_PEAK_TFLOPS * 1e12), 4),
     }
+
+    extras = {} if args.no_extras else tfam_extras(dev, rank, world, cdt)
+    result["extras"] = extras
 
     if rank == 0:
         # ---- roofline of the GEMM family: instrument every vmc_linear launch with HIP events --------
