@@ -103,6 +103,12 @@ int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype
 int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y16, float* y32,
                       float* mean, float* rstd, int rows, int D, int ldx, float eps, int x_dtype,
                       int dtype16, void* stream);
+/* Fused residual update + LayerNorm of the pre-LN ViT blocks: x (fp32 residual stream, row stride ldx) <- x +
+ * branch (16-bit attention / MLP branch output, row stride ldb), written back when write_x != 0, and
+ * y16 [rows, D] = LN(x).  Replaces `x = x + attn(...)` / `x = x + mlp(...)` followed by ln_2 / the next ln_1 /
+ * ln_post (OpenAI clip ResidualAttentionBlock.forward).  D % 256 == 0, D <= 2048. */
+int vmc_add_layernorm_fwd(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows,
+                          int D, int ldx, int ldb, float eps, int write_x, int dtype16, void* stream);
 /* Backward (autograd of the LayerNorms, train.py:104): dx [rows,D] (f32 or 16-bit per dx_dtype) =
  * LN'(dy) + add, where `add` (optional, dx's dtype/layout) is the gradient arriving over the residual
  * branch that forks at x (fused so the fork needs no separate add pass).  dgamma/dbeta f32 [D],

@@ -19,22 +19,24 @@ def main():
     ap.add_argument("--shapes", nargs="*", default=DEFAULT)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--epilogue", action="store_true", help="bias + QuickGELU + fp32 residual like the encoder")
+    ap.add_argument("--act", type=int, default=0, help="0 none, 1 QuickGELU (adds a bias too)")
+    ap.add_argument("--res32", action="store_true", help="fp32 residual in + fp32 out in place (out_proj / c_proj epilogue)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     for s in args.shapes:
         M, N, K = map(int, s.split(","))
         a = torch.randn(M, K, device="cuda").to(dt)
         w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
-        out = torch.empty(M, N, device="cuda", dtype=dt)
-        bias = torch.randn(N, device="cuda") if args.epilogue else None
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if args.res32 else dt)
+        bias = torch.randn(N, device="cuda") if (args.act or args.res32) else None
+        kw = dict(bias=bias, out=out, act=args.act, res=out if args.res32 else None)
         for _ in range(3):
-            ops.linear(a, w, bias=bias, out=out)
+            ops.linear(a, w, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.linear(a, w, bias=bias, out=out)
+            ops.linear(a, w, **kw)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters

@@ -138,18 +138,38 @@ class VisionTransformer(nn.Module):
             ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias, dt16, out16=False, out32=True, y32=x)
         else:
             self._ln_inplace16(x, self.ln_pre)
-        for i, blk in enumerate(self.transformer.resblocks):
+        fused = xf32 and D % 256 == 0          # residual add fused into the next LayerNorm (vmc_add_layernorm_fwd)
+        blocks = list(self.transformer.resblocks)
+        h = None
+        for i, blk in enumerate(blocks):
             pre = f"blk{i}."
-            h, *_ = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, dt16)
+            if h is None:
+                h, *_ = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, dt16)
             qkv = ops.linear(h, self.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
             o, _ = ops.attention_vit(qkv, F, N, H)
             del qkv
-            ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x, out=x)
-            h, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16)
+            if fused:
+                a = ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)
+                h = ops.add_layernorm_(x, a, blk.ln_2.weight, blk.ln_2.bias)
+            else:
+                ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x, out=x)
+                h, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16)
             u = ops.linear(h, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
-            ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=x, out=x)
-            del u, h, o
-        cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
+            last = i + 1 == len(blocks)
+            if fused:
+                m = ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias)
+                if last:       # only the class rows are needed after the last block: x[cls] + m[cls] -> ln_post
+                    cls = ops.add_layernorm_(x, m, self.ln_post.weight, self.ln_post.bias, rows=F, ldx=N * D, ldb=N * D, write_x=False)
+                else:
+                    nxt = blocks[i + 1]
+                    h = ops.add_layernorm_(x, m, nxt.ln_1.weight, nxt.ln_1.bias)
+                del m
+            else:
+                ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=x, out=x)
+                h = None
+                if last:
+                    cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
+            del u, o
         return ops.linear(cls, self.w16("proj", self.proj, transposed=True), out_dtype=torch.float32)
 
     def _ln_inplace16(self, x, ln):

@@ -93,6 +93,92 @@ extern "C" int vmc_layernorm_fwd(const void* x, const float* gamma, const float*
   return 0;
 }
 
+// ---- fused residual add + LayerNorm ---------------------------------------------------------------
+// x <- x + branch (fp32 residual stream updated in place), y16 = LN(x).  Keeps the residual update out of
+// the GEMM epilogues (where 2 x 256 KB per tile of fp32 traffic is serialised behind a 1-block-per-CU
+// main loop) and puts it in this HBM-streaming kernel instead.  CH = D / 256 chunks per lane, compile time.
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, const uint16_t* __restrict__ branch,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     uint16_t* __restrict__ y16, int rows, size_t ldx, size_t ldb, float eps,
+                                                     int write_x) {
+  constexpr int D = CH * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  float4 g[CH], b[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    g[c] = *(const float4*)(gamma + c * 256 + lane * 4);
+    b[c] = *(const float4*)(beta + c * 256 + lane * 4);
+  }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    float4 v[CH];
+    uint2 br[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      v[c] = *(const float4*)(x + (size_t)row * ldx + c * 256 + lane * 4);
+      br[c] = *(const uint2*)(branch + (size_t)row * ldb + c * 256 + lane * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float a0, a1, a2, a3;
+      unpack2<T>(br[c].x, a0, a1);
+      unpack2<T>(br[c].y, a2, a3);
+      v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      if (write_x) *(float4*)(x + (size_t)row * ldx + c * 256 + lane * 4) = v[c];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float p = v[c].x - mean, q = v[c].y - mean, r = v[c].z - mean, t = v[c].w - mean;
+      ss += (p * p + q * q) + (r * r + t * t);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.0f / D) + eps);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float o0 = (v[c].x - mean) * rstd * g[c].x + b[c].x, o1 = (v[c].y - mean) * rstd * g[c].y + b[c].y;
+      const float o2 = (v[c].z - mean) * rstd * g[c].z + b[c].z, o3 = (v[c].w - mean) * rstd * g[c].w + b[c].w;
+      *(uint2*)(y16 + (size_t)row * D + c * 256 + lane * 4) = make_uint2(pack2<T>(o0, o1), pack2<T>(o2, o3));
+    }
+  }
+}
+
+template <typename T>
+static int launch_add_ln(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows, int D, size_t ldx,
+                         size_t ldb, float eps, int write_x, hipStream_t s) {
+  const int grid = grid_for((size_t)rows, 4, 256 * 8);
+#define VMC_ADDLN(CHN)                                                                                                        \
+  hipLaunchKernelGGL((add_ln_kernel<T, CHN>), dim3(grid), dim3(256), 0, s, x, (const uint16_t*)branch, gamma, beta, (uint16_t*)y16, \
+                     rows, ldx, ldb, eps, write_x)
+  switch (D / 256) {
+    case 1: VMC_ADDLN(1); break;
+    case 2: VMC_ADDLN(2); break;
+    case 3: VMC_ADDLN(3); break;
+    case 4: VMC_ADDLN(4); break;
+    case 5: VMC_ADDLN(5); break;
+    case 6: VMC_ADDLN(6); break;
+    case 8: VMC_ADDLN(8); break;
+    default: return VMC_E_SHAPE;
+  }
+#undef VMC_ADDLN
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vmc_add_layernorm_fwd(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows, int D,
+                                     int ldx, int ldb, float eps, int write_x, int dtype16, void* stream) {
+  if (!x || !branch || !gamma || !beta || !y16 || rows <= 0 || D <= 0) return VMC_E_ARG;
+  if (D % 256 || D > 2048) return VMC_E_SHAPE;
+  if (ldx % 4 || ldb % 4 || ldx < D || ldb < D) return VMC_E_ALIGN;
+  if (dtype16 == VMC_BF16) return launch_add_ln<BF16>(x, branch, gamma, beta, y16, rows, D, ldx, ldb, eps, write_x, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return launch_add_ln<F16>(x, branch, gamma, beta, y16, rows, D, ldx, ldb, eps, write_x, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
 // ---- backward ---------------------------------------------------------------------------------
 // dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));  dgamma = sum_rows g*xhat;  dbeta = sum_rows g.
 // Each wave accumulates its rows' dgamma/dbeta partials in registers, then one partial row per block

@@ -89,6 +89,17 @@ def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False,
     return y16, y32, mean, rstd
 
 
+def add_layernorm_(x32: torch.Tensor, branch16: torch.Tensor, gamma, beta, *, rows=None, ldx=None, ldb=None, write_x=True,
+                   eps: float = 1e-5) -> torch.Tensor:
+    """x32 += branch16 (in place, fp32 residual stream) and return LN(x32) in branch16's dtype (vmc_add_layernorm_fwd)."""
+    D = gamma.shape[0]
+    rows = x32.numel() // D if rows is None else rows
+    y = torch.empty((rows, D), dtype=branch16.dtype, device=x32.device)
+    check(lib.vmc_add_layernorm_fwd(ptr(x32), ptr(branch16), ptr(gamma), ptr(beta), ptr(y), rows, D, ldx or D, ldb or D, float(eps),
+                                    int(write_x), dt(branch16), stream()), "add_layernorm_fwd")
+    return y
+
+
 def attention_vit(qkv: torch.Tensor, F: int, N: int, H: int, want_lse: bool = False):
     D = H * 64
     out = torch.empty((F * N, D), dtype=qkv.dtype, device=qkv.device)
