@@ -78,6 +78,11 @@ int vmc_linear(const void* A, const void* W, const float* bias, const void* res,
                int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                int dtype16, void* stream);
 
+/* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
+ * 1 = 8-phase 256x256 kernel, one tile per workgroup (default), 2 = persistent 8-phase kernel.  Results are
+ * identical bit for bit across the three. */
+int vmc_set_gemm_variant(int variant);
+
 /* 16-bit 2-D transpose  out[c, r] = in[r, c]  (rows x cols, element strides ld_in / ld_out); used for
  * the dgrad/wgrad operand layouts of K8 (autograd of F.linear, train.py:104). */
 int vmc_transpose16(const void* in, void* out, int rows, int cols, int ld_in, int ld_out, void* stream);

@@ -26,6 +26,7 @@ SIGNATURES = {
     "vmc_preprocess_patches_u8": (I, [P, P, I, I, I, I, I, I, P]),
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
+    "vmc_set_gemm_variant": (I, [I]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),
     "vmc_colsum_workspace_bytes": (Z, [I, I]),

@@ -27,16 +27,31 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   const uint16_t* base = qkv + (size_t)f * N * ld + h * 64;
 
   // ---- stage K and V (zero rows for padded keys) ----
-  for (int idx = tid; idx < NKEYS * 8; idx += 256) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (row < N) {
-      const uint16_t* p = base + (size_t)row * ld + c * 8;
-      kv = *(const uint4*)(p + D);
-      vv = *(const uint4*)(p + 2 * D);
+  // all loads first (NKEYS*8/256 <= 9 chunks of K and of V per thread, registers are free before the compute
+  // phase), then all LDS writes: one exposed HBM/L2 latency per block instead of one per chunk
+  {
+    constexpr int ITERS = NKEYS * 8 / 256 > 0 ? NKEYS * 8 / 256 : 1;
+    uint4 kreg[ITERS], vreg[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 3, c = idx & 7;
+      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
+      if (idx < NKEYS * 8 && row < N) {
+        const uint16_t* p = base + (size_t)row * ld + c * 8;
+        kreg[i] = *(const uint4*)(p + D);
+        vreg[i] = *(const uint4*)(p + 2 * D);
+      }
     }
-    *(uint4*)(k_lds + lds_off_x(row, c)) = kv;
-    *(uint4*)(v_lds + lds_off_v(row, c)) = vv;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 3, c = idx & 7;
+      if (idx < NKEYS * 8) {
+        *(uint4*)(k_lds + lds_off_x(row, c)) = kreg[i];
+        *(uint4*)(v_lds + lds_off_v(row, c)) = vreg[i];
+      }
+    }
   }
   __syncthreads();
 
@@ -68,43 +83,38 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
         s[nt] = T::mfma16(kf, qf[kk], s[nt]);
       }
     }
-    // ---- softmax over the row (keys >= N masked) ----
-    float m = -INFINITY;
+    // ---- softmax over the row.  Only tiles that can hold padded keys (>= N) are masked; the row sum comes
+    //      from an MFMA against a ones operand (the MFMA pipe is idle here, the VALU is the busy unit) ----
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
+      if (16 * nt + 16 > N) {  // wave-uniform
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = 16 * nt + 4 * q + j;
-        if (key >= N) s[nt][j] = -INFINITY;
-        m = fmaxf(m, s[nt][j]);
+        for (int j = 0; j < 4; ++j)
+          if (16 * nt + 4 * q + j >= N) s[nt][j] = -INFINITY;
       }
+    float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) m = fmaxf(fmaxf(fmaxf(m, s[nt][0]), fmaxf(s[nt][1], s[nt][2])), s[nt][3]);
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = __builtin_amdgcn_exp2f((s[nt][j] - m) * c2);
-        s[nt][j] = p;
-        sum += p;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
+    const float mc = m * c2;
 
-    // ---- O^T = V^T P^T ----
-    f32x4 o[4];
+    // ---- O^T = V^T P^T, rowsum = 1^T P^T ----
+    f32x4 o[4], osum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
 #pragma unroll
     for (int ks = 0; ks < NT / 2; ++ks) {
       uint4 pf;
-      pf.x = pack2<T>(s[2 * ks][0], s[2 * ks][1]);
-      pf.y = pack2<T>(s[2 * ks][2], s[2 * ks][3]);
-      pf.z = pack2<T>(s[2 * ks + 1][0], s[2 * ks + 1][1]);
-      pf.w = pack2<T>(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+      {
+        const f32x4 a = s[2 * ks], b = s[2 * ks + 1];
+        pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[1], c2, -mc)));
+        pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[3], c2, -mc)));
+        pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[1], c2, -mc)));
+        pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[3], c2, -mc)));
+      }
+      osum = T::mfma16(ones, pf, osum);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // 4-key x 16-column blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block:
@@ -117,6 +127,9 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
         o[dt] = T::mfma16(vf, pf, o[dt]);
       }
     }
+    const float sum = osum[0];   // every accumulator row holds the full row sum of query r (16-bit rounded P, as P V uses)
+    const float inv = 1.0f / sum;
+    if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
     if (qrow < N) {
       uint16_t* orow = out + ((size_t)f * N + qrow) * D + h * 64 + 4 * q;
 #pragma unroll

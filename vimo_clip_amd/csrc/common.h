@@ -10,6 +10,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define VMC_LDS __attribute__((address_space(3)))
 #define VMC_GLOBAL __attribute__((address_space(1)))
@@ -28,6 +31,10 @@ struct BF16 {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(uint16_t, b);
   }
+  __device__ static inline uint32_t pack(float lo, float hi) {  // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+  }
+  static constexpr uint32_t ONE_PAIR = 0x3F803F80u;  // (1.0, 1.0)
   __device__ static inline f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
@@ -39,6 +46,10 @@ struct F16 {
     _Float16 h = (_Float16)f;
     return __builtin_bit_cast(uint16_t, h);
   }
+  __device__ static inline uint32_t pack(float lo, float hi) {  // one v_cvt_pk_f16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, f16x2));
+  }
+  static constexpr uint32_t ONE_PAIR = 0x3C003C00u;  // (1.0, 1.0)
   __device__ static inline f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -46,7 +57,7 @@ struct F16 {
 
 template <typename T>
 __device__ inline uint32_t pack2(float lo, float hi) {
-  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+  return T::pack(lo, hi);
 }
 template <typename T>
 __device__ inline void unpack2(uint32_t w, float& lo, float& hi) {

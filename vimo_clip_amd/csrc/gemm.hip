@@ -231,6 +231,17 @@ static int launch_act(GemmArgs& g, int act, hipStream_t stream) {
   return VMC_E_ARG;
 }
 
+static int g_gemm_variant = []() {
+  const char* e = getenv("VMC_GEMM8");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+}();
+int vmc_gemm_variant() { return g_gemm_variant; }
+extern "C" int vmc_set_gemm_variant(int v) {
+  if (v < 0 || v > 2) return VMC_E_ARG;
+  g_gemm_variant = v;
+  return 0;
+}
+
 extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const void* res, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                           int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
@@ -251,9 +262,8 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   g.tiles_m = g.tiles_n = 0;
   // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
   // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
-  static const bool use_g8 = []() { const char* e = getenv("VMC_GEMM8"); return !(e && e[0] == '0'); }();
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (use_g8 && t256 >= 192 && (K % 128) == 0) return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
+  if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
   if (dtype16 == VMC_BF16) return launch_act<BF16>(g, act, (hipStream_t)stream);
   return launch_act<F16>(g, act, (hipStream_t)stream);
 }

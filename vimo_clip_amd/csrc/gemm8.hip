@@ -79,6 +79,14 @@ __device__ __forceinline__ void g8_mma(f32x4 (&acc)[4][2], const uint4 (&a)[4][2
 }
 
 #define G8_WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+// First K tile of a persistent output tile: the previous tile's epilogue stores (ns per wave, counted exactly)
+// sit in the vmcnt queue BEHIND the already-issued LDS-DMAs of this tile and in front of the new ones, so they
+// may stay outstanding: allow 8 + ns.  Any other count falls back to the conservative vmcnt(8).
+__device__ __forceinline__ void g8_wait8_plus(int ns) {
+  if (ns == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (ns == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
 // Two K tiles (even slots *e, odd slots *o).  k1/k2/k3 = byte offsets of tiles t+1, t+2, t+3 (clamped).
 template <typename T>
@@ -123,8 +131,25 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
 
+  // Tile order: each XCD walks a contiguous id range (xcd_remap); ids run over column GROUPS of 4 tiles, rows
+  // inside a group.  The 32 tiles an XCD runs at once are then 8 row panels x 4 column panels: the 4 W panels
+  // (2 MB at K = 1024) stay resident in that XCD's 4 MB L2 for the whole sweep and only A panels stream.
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+  int tm, tn;
+  {
+    constexpr int GC = 4;
+    const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
+    const int cg = tile / gsz;
+    if (cg < nfull) {
+      const int rem = tile - cg * gsz;
+      tm = rem / GC;
+      tn = cg * GC + rem % GC;
+    } else {
+      const int w = g.tiles_n - nfull * GC, rem = tile - nfull * gsz;
+      tm = rem / w;
+      tn = nfull * GC + rem % w;
+    }
+  }
   const int m0 = tm * 256, n0 = tn * 256;
 
   const char *sA0[2], *sA1[2], *sB0[2], *sB1[2];
@@ -197,6 +222,220 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
     }
 }
 
+
+// ==================================================================================================
+// Persistent variant: 256 workgroups (one per CU) walk the tile list of their XCD; the LDS-DMA pipeline
+// runs straight through tile boundaries (the last phases of tile j stage the first 1.5 K tiles of tile
+// j+1, exactly the prologue set, into the slots the schedule would use anyway), so the per-tile prologue
+// latency and the workgroup relaunch are gone and the epilogue stores overlap the next tile's loads.
+// Staging uses buffer_load ... lds: one descriptor per operand, per-lane offset in a VGPR, tile / half /
+// K offset in an SGPR; rows past M (or N) fall outside the descriptor and read as zeros.
+// ==================================================================================================
+// The bounds check of a raw buffer access covers voffset (+ immediate) but, depending on the generation, not
+// soffset: the tile's ROW offset therefore travels in the VGPR offset (rows >= M or >= N then fall outside the
+// descriptor and read as zeros whichever way the hardware checks) and only the small K offset is scalar.
+__device__ __forceinline__ void g8p_stage(__amdgpu_buffer_rsrc_t rsrc, char* slot, const int (&voff)[2], int row_off, int k_off,
+                                          int wave_lds) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (VMC_LDS void*)(slot + i * 8192 + wave_lds), 16, voff[i] + row_off, k_off, 0, 0);
+}
+
+struct G8Offs {   // per K tile t+1, t+2, t+3 (t+2, t+3 possibly in the next output tile): row byte offsets of the A / W
+  int ar1, br1, k1, ar2, br2, k2, ar3, br3, k3;   // tile and the K byte offset
+};
+
+template <typename T>
+__device__ __forceinline__ void g8p_iter(char* A0e, char* A1e, char* B0e, char* B1e, char* A0o, char* A1o, char* B0o, char* B1o,
+                                         __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const int (&va)[2], const int (&vb)[2],
+                                         const G8Offs o, int HA, int HB, int wave_lds, const int (&xoff)[2],
+                                         const int (&woff)[2][2], f32x4 (&acc)[2][2][4][2], G8Frags<T>& f, int ns) {
+  // ---- even tile ----
+  g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
+  g8p_stage(rb, B1o, vb, o.br1 + HB, o.k1, wave_lds); g8_wait8_plus(ns);
+  g8_mma<T>(acc[0][0], f.a, f.b0);
+  g8_read_b(B1e, woff, f.b1);
+  g8p_stage(ra, A1o, va, o.ar1 + HA, o.k1, wave_lds); g8_wait8_plus(ns);
+  g8_mma<T>(acc[0][1], f.a, f.b1);
+  g8_read_a(A1e, xoff, f.a);
+  g8p_stage(ra, A0e, va, o.ar2, o.k2, wave_lds);
+  g8_mma<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0e, vb, o.br2, o.k2, wave_lds); g8_wait8_plus(ns);
+  g8_mma<T>(acc[1][0], f.a, f.b0);
+  // ---- odd tile ----
+  g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
+  g8p_stage(rb, B1e, vb, o.br2 + HB, o.k2, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[0][0], f.a, f.b0);
+  g8_read_b(B1o, woff, f.b1);
+  g8p_stage(ra, A1e, va, o.ar2 + HA, o.k2, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[0][1], f.a, f.b1);
+  g8_read_a(A1o, xoff, f.a);
+  g8p_stage(ra, A0o, va, o.ar3, o.k3, wave_lds);
+  g8_mma<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0o, vb, o.br3, o.k3, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[1][0], f.a, f.b0);
+}
+
+__device__ __forceinline__ void g8_tile_coords(const GemmArgs& g, int tile, int& tm, int& tn) {
+  constexpr int GC = 4;   // column groups of 4 tiles: see gemm8_kernel
+  const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
+  const int cg = tile / gsz;
+  if (cg < nfull) {
+    const int rem = tile - cg * gsz;
+    tm = rem / GC;
+    tn = cg * GC + rem % GC;
+  } else {
+    const int w = g.tiles_n - nfull * GC, rem = tile - nfull * gsz;
+    tm = rem / w;
+    tn = nfull * GC + rem % w;
+  }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+
+  // this workgroup's tile list: ids first + 32*j inside the contiguous range of its XCD group
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + slot;
+  const int end = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tq + (xcd < tr ? 1 : 0);
+  if (first >= end) return;   // (whole workgroup; never happens for ntiles >= gridDim.x)
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
+  int va[2], vb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, ch;
+    stage_src_x(i * 512 + tid, row, ch);
+    va[i] = (row * g.lda + ch * 8) * 2;
+    stage_src_w8(i * 512 + tid, row, ch);
+    vb[i] = (row * g.ldw + ch * 8) * 2;
+  }
+  const int HA = 128 * g.lda * 2, HB = 128 * g.ldw * 2;   // second half-tile (rows +128)
+  const int wave_lds = wave * 1024;
+  int xoff[2], woff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    xoff[kk] = lds_off_x(64 * wm + r, 4 * kk + q);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) woff[kk][nt] = lds_off_w8(32 * wn + g8_w_row(r, nt), 4 * kk + q);
+  }
+  char* const A0e = smem + 0 * G8_SLOT; char* const A1e = smem + 1 * G8_SLOT;
+  char* const B0e = smem + 2 * G8_SLOT; char* const B1e = smem + 3 * G8_SLOT;
+  char* const A0o = smem + 4 * G8_SLOT; char* const A1o = smem + 5 * G8_SLOT;
+  char* const B0o = smem + 6 * G8_SLOT; char* const B1o = smem + 7 * G8_SLOT;
+
+  const int nkt = g.K >> 6;  // even, >= 2
+  int tm, tn;
+  g8_tile_coords(g, first, tm, tn);
+  int abase = tm * 256 * g.lda * 2, bbase = tn * 256 * g.ldw * 2;
+  // prologue of the first tile (same issue order as the steady state)
+  g8p_stage(ra, A0e, va, abase, 0, wave_lds); g8p_stage(rb, B0e, vb, bbase, 0, wave_lds); g8p_stage(rb, B1e, vb, bbase + HB, 0, wave_lds);
+  g8p_stage(ra, A1e, va, abase + HA, 0, wave_lds); g8p_stage(ra, A0o, va, abase, 128, wave_lds); g8p_stage(rb, B0o, vb, bbase, 128, wave_lds);
+  G8_WAIT8();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+
+  const bool vec8 = gemm_vec8_ok(g);
+  G8Frags<T> f;
+  int ns = 0;   // store instructions this wave issued in the previous tile's epilogue
+  for (int tile = first; tile < end; tile += per) {
+    const int m0 = tm * 256, n0 = tn * 256;
+    // next output tile (or this one again when the list ends: the tail prefetches stay in bounds and are never read)
+    int ntm = tm, ntn = tn;
+    const bool has_next = tile + per < end;
+    if (has_next) g8_tile_coords(g, tile + per, ntm, ntn);
+    const int nabase = ntm * 256 * g.lda * 2, nbbase = ntn * 256 * g.ldw * 2;
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nkt; t += 2) {
+      G8Offs o;
+      // K tile t+1 always belongs to this output tile (nkt even); t+2 and t+3 roll over into the next one
+      o.ar1 = abase; o.br1 = bbase; o.k1 = (t + 1) * 128;
+      if (t + 2 < nkt) {
+        o.ar2 = o.ar3 = abase; o.br2 = o.br3 = bbase;
+        o.k2 = (t + 2) * 128; o.k3 = (t + 3) * 128;
+      } else if (has_next) {
+        o.ar2 = o.ar3 = nabase; o.br2 = o.br3 = nbbase;
+        o.k2 = 0; o.k3 = 128;
+      } else {
+        o.ar2 = o.ar3 = abase; o.br2 = o.br3 = bbase;
+        o.k2 = o.k3 = (nkt - 1) * 128;
+      }
+      g8p_iter<T>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, va, vb, o, HA, HB, wave_lds, xoff, woff, acc, f, t == 0 ? ns : 0);
+    }
+
+    // epilogue of this tile; the next tile's first K tiles are already in flight
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int row = m0 + 128 * mh + 64 * wm + 16 * mt + r;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          float v[8];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mh][nh][mt][nt][j];
+          gemm_epilogue_row<T, ACT, 8>(g, row, n0 + 128 * nh + 32 * wn + 8 * q, v, vec8);
+        }
+      }
+    {  // exact count of the store instructions this wave just executed (a store runs if any lane has work)
+      int rows_on = 0, segs_on = 0;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) rows_on += (m0 + 128 * mh + 64 * wm + 16 * mt) < g.M;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int cb = n0 + 128 * nh + 32 * wn;
+        if (!g.out_f32 && vec8) segs_on += cb < g.N;
+        else segs_on += (cb < g.N) + (cb + 4 < g.N);
+      }
+      ns = __builtin_amdgcn_readfirstlane(rows_on * segs_on);
+    }
+    tm = ntm; tn = ntn; abase = nabase; bbase = nbbase;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+}
+
+template <typename T, int ACT>
+static int g8p_launch(GemmArgs& g, hipStream_t stream) {
+  auto kern = gemm8p_kernel<T, ACT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int grid = ntiles >= 256 ? 256 : (ntiles / 8) * 8;   // multiple of 8: one slot list per XCD group
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 8 * G8_SLOT, stream, g);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int ACT>
 static int g8_launch(GemmArgs& g, hipStream_t stream) {
   auto kern = gemm8_kernel<T, ACT>;
@@ -215,6 +454,18 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
 
 template <typename T>
 static int g8_act(GemmArgs& g, int act, hipStream_t s) {
+  // persistent kernel unless an operand does not fit a 2 GiB buffer descriptor (VMC_GEMM8=1 forces the
+  // one-tile-per-workgroup kernel for A/B measurements)
+  const bool fits = (size_t)g.M * g.lda * 2 < (1ull << 31) && (size_t)g.N * g.ldw * 2 < (1ull << 31);
+  if (fits && vmc_gemm_variant() == 2) {
+    switch (act) {
+      case VMC_ACT_NONE: return g8p_launch<T, VMC_ACT_NONE>(g, s);
+      case VMC_ACT_QUICKGELU: return g8p_launch<T, VMC_ACT_QUICKGELU>(g, s);
+      case VMC_ACT_GELU_ERF: return g8p_launch<T, VMC_ACT_GELU_ERF>(g, s);
+      case VMC_ACT_RELU: return g8p_launch<T, VMC_ACT_RELU>(g, s);
+    }
+    return VMC_E_ARG;
+  }
   switch (act) {
     case VMC_ACT_NONE: return g8_launch<T, VMC_ACT_NONE>(g, s);
     case VMC_ACT_QUICKGELU: return g8_launch<T, VMC_ACT_QUICKGELU>(g, s);

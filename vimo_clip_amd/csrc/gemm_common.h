@@ -71,5 +71,9 @@ __device__ __forceinline__ bool gemm_vec8_ok(const GemmArgs& g) {
   return ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.res == nullptr || (g.ldres & 7) == 0);
 }
 
+// Large-GEMM kernel selection (vmc_set_gemm_variant): 0 two-stage tiles only, 1 8-phase one tile per workgroup,
+// 2 8-phase persistent.  Initialised from the environment variable VMC_GEMM8, default in gemm.hip.
+int vmc_gemm_variant();
+
 // 8-phase 256x256 kernel family (gemm8.hip); returns VMC_E_SHAPE when the shape does not qualify.
 int vmc_gemm8_launch(GemmArgs& g, int act, int dtype16, hipStream_t stream);
