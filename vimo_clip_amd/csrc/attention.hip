@@ -11,6 +11,84 @@
 //   the exponentiated accumulators are directly the B operand of O^T = V^T P^T with the k-slots
 //   permuted (tile_index.h attn_pv_key); V^T fragments come from ds_read_b64_tr_b16.
 // ==================================================================================================
+// One chunk of NKS 32-key steps starting at step KS0 for a 16-query tile: S^T = K Q^T, running max update,
+// rescale of the accumulators, P = exp2(c2 s - c2 m) packed to 16 bits, O^T += V^T P^T, rowsum += 1^T P^T.
+template <typename T, int KS0, int NKS>
+__device__ __forceinline__ void attn_chunk(const char* k_lds, const char* v_lds, int koff0, int koff1, const int (&voff)[4],
+                                           const uint4 (&qf)[2], int N, int q, float c2, float& m, f32x4 (&o)[4], f32x4& osum) {
+  constexpr int NTC = 2 * NKS, NT0 = 2 * KS0;
+  f32x4 s[NTC];
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) {
+    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    s[t] = T::mfma16(*(const uint4*)(k_lds + koff0 + (NT0 + t) * 2048), qf[0], s[t]);
+    s[t] = T::mfma16(*(const uint4*)(k_lds + koff1 + (NT0 + t) * 2048), qf[1], s[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < NTC; ++t)
+    if (16 * (NT0 + t) + 16 > N) {  // wave-uniform: only tiles that can hold padded keys are masked
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (16 * (NT0 + t) + 4 * q + j >= N) s[t][j] = -INFINITY;
+    }
+  float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+  for (int t = 1; t < NTC; ++t) mx = fmaxf(fmaxf(fmaxf(mx, s[t][0]), fmaxf(s[t][1], s[t][2])), s[t][3]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mnew = fmaxf(m, mx);          // key 0 is always valid, so mnew is finite from the first chunk on
+  if (KS0 > 0) {                            // rescale what the earlier chunk accumulated (exp2(-inf) never occurs here)
+    const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    osum *= alpha;
+  }
+  m = mnew;
+  const float mc = mnew * c2;
+  uint4 pf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const f32x4 a = s[2 * ks], b = s[2 * ks + 1];
+    pf[ks].x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[1], c2, -mc)));
+    pf[ks].y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[3], c2, -mc)));
+    pf[ks].z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[1], c2, -mc)));
+    pf[ks].w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[3], c2, -mc)));
+  }
+  const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
+  // V^T fragments: 4-key x 16-column transposed blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block:
+  // keys 32 ks + 4 q + (r>>2) (+16 for the second block); the swizzle does not depend on ks (tile_index.h)
+  // explicit one-step-ahead double buffer: without it hipcc issues each pair of transposed reads right in front of
+  // the MFMA that consumes it (lgkmcnt(0) per MFMA)
+  auto load_v = [&](int ks, s16x4 (&v0)[4], s16x4 (&v1)[4]) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      v0[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + (KS0 + ks) * 4096));
+      v1[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + (KS0 + ks) * 4096 + 2048));
+    }
+  };
+  auto mma_v = [&](int ks, const s16x4 (&v0)[4], const s16x4 (&v1)[4]) {
+    osum = T::mfma16(ones, pf[ks], osum);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint4 vf;
+      const uint2 a = __builtin_bit_cast(uint2, v0[dt]), b = __builtin_bit_cast(uint2, v1[dt]);
+      vf.x = a.x; vf.y = a.y; vf.z = b.x; vf.w = b.y;
+      o[dt] = T::mfma16(vf, pf[ks], o[dt]);
+    }
+  };
+  s16x4 va0[4], va1[4], vb0[4], vb1[4];
+  load_v(0, va0, va1);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks += 2) {
+    if (ks + 1 < NKS) load_v(ks + 1, vb0, vb1);
+    mma_v(ks, va0, va1);
+    if (ks + 1 < NKS) {
+      if (ks + 2 < NKS) load_v(ks + 2, va0, va1);
+      mma_v(ks + 1, vb0, vb1);
+    }
+  }
+}
+
 template <typename T, int NT>
 __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, float scale) {
@@ -73,60 +151,16 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
       for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(qrow + 64, N - 1) * ld + (4 * kk + q) * 8);
     }
 
-    f32x4 s[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4 kf = *(const uint4*)(k_lds + (kk ? koff1 : koff0) + nt * 2048);
-        s[nt] = T::mfma16(kf, qf[kk], s[nt]);
-      }
-    }
-    // ---- softmax over the row.  Only tiles that can hold padded keys (>= N) are masked; the row sum comes
-    //      from an MFMA against a ones operand (the MFMA pipe is idle here, the VALU is the busy unit) ----
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      if (16 * nt + 16 > N) {  // wave-uniform
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (16 * nt + 4 * q + j >= N) s[nt][j] = -INFINITY;
-      }
-    float m = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
-#pragma unroll
-    for (int nt = 1; nt < NT; ++nt) m = fmaxf(fmaxf(fmaxf(m, s[nt][0]), fmaxf(s[nt][1], s[nt][2])), s[nt][3]);
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float mc = m * c2;
-
-    // ---- O^T = V^T P^T, rowsum = 1^T P^T ----
+    // Keys are processed in one or two chunks (online softmax across chunks): two chunks keep the live score
+    // registers at <= 40 (N = 257: 10 + 8 tiles) so nothing spills at 2 waves/SIMD and the LDS reads pipeline.
     f32x4 o[4], osum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
-#pragma unroll
-    for (int ks = 0; ks < NT / 2; ++ks) {
-      uint4 pf;
-      {
-        const f32x4 a = s[2 * ks], b = s[2 * ks + 1];
-        pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[1], c2, -mc)));
-        pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[3], c2, -mc)));
-        pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[1], c2, -mc)));
-        pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(b[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(b[3], c2, -mc)));
-      }
-      osum = T::mfma16(ones, pf, osum);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        // 4-key x 16-column blocks; this lane supplies row (r>>2), columns 4*(r&3).. of each block:
-        // keys 32 ks + 4 q + (r>>2) (+16 for the second block); the swizzle does not depend on ks
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + ks * 4096));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(v_lds + voff[dt] + ks * 4096 + 2048));
-        uint4 vf;
-        const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
-        vf.x = a.x; vf.y = a.y; vf.z = b.x; vf.w = b.y;
-        o[dt] = T::mfma16(vf, pf, o[dt]);
-      }
-    }
+    float m = -INFINITY;
+    constexpr int KS = NT / 2;                         // 32-key steps
+    constexpr int KA = NT >= 14 ? (KS + 1) / 2 : KS;   // steps in the first chunk
+    attn_chunk<T, 0, KA>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
+    if constexpr (KS > KA) attn_chunk<T, KA, KS - KA>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
     const float sum = osum[0];   // every accumulator row holds the full row sum of query r (16-bit rounded P, as P V uses)
     const float inv = 1.0f / sum;
     if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
