@@ -268,6 +268,22 @@ def main():
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
     print("metrics.npz", len(out))
 
+    # ---------------- Animal Kingdom annotations (data shipped with the reference): label subset ----------------
+    # BASELINE.json configs[4] trains on the AK annotations with synthetic embeddings; the first 768 train and 256 val
+    # lines (video id + class ids, parsed as extract_embeddings.py:46-47,97-103 does) are kept as a data fixture.
+    out = {}
+    for split, n in (("train", 768), ("val", 256)):
+        with open(os.path.join(REF, "dataset", "annotations", f"{split}_multi.txt"), "r", encoding="utf-8") as f:
+            ann = [line.strip().split() for line in f if line.strip()][:n]
+        lab = np.zeros((len(ann), 140), dtype=np.uint8)
+        for i, a in enumerate(ann):
+            for c in a[1:]:
+                lab[i, int(c)] = 1
+        out[f"{split}/labels"] = np.packbits(lab, axis=1)
+        out[f"{split}/ids"] = np.array([a[0] for a in ann])
+    np.savez_compressed(os.path.join(OUT, "ak_labels.npz"), **out)
+    print("ak_labels.npz", {k: v.shape for k, v in out.items()})
+
     with open(os.path.join(OUT, "META.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
