@@ -86,8 +86,8 @@ class AttentionLayer(nn.Module):
             xr, xg = ag.fork(x32, dt16)
             x16 = ag.cast(xg, dt16)
             W, b = self.cross_attn.in_proj_weight, self.cross_attn.in_proj_bias
-            q = ag.linear(x16, _RowSlice.apply(W, 0, D), _RowSlice.apply(b, 0, D))
-            kv = ag.linear(cross16, _RowSlice.apply(W, D, 3 * D), _RowSlice.apply(b, D, 3 * D))
+            q = ag.linear(x16, W, b, rows=(0, D))              # _in_projection_packed: q from rows 0:D,
+            kv = ag.linear(cross16, W, b, rows=(D, 3 * D))      # k | v from rows D:3D of the packed in_proj
             o = _CrossAttn.apply(q, kv, cross_mask_u8, B, T, Tk, H, p, seed_fn() if p > 0 else 0)
             o = ag.linear(o, self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias)
             o = ag.dropout(o, p, tr, seed_fn)
@@ -120,28 +120,6 @@ class _Add32(torch.autograd.Function):
 
 def _add32(a, b, dt16):
     return _Add32.apply(a, b, dt16)
-
-
-class _RowSlice(torch.autograd.Function):
-    """Rows [lo, hi) of a parameter (the q / kv thirds of in_proj_weight, F.multi_head_attention_forward's
-    ``_in_projection_packed``); the backward writes the slice of the gradient into a zero tensor (or the
-    parameter's arena slot rows) — memory plumbing only."""
-
-    @staticmethod
-    def forward(ctx, w, lo, hi):
-        ctx.w, ctx.lo, ctx.hi = w, lo, hi
-        return w.detach()[lo:hi]
-
-    @staticmethod
-    def backward(ctx, g):
-        w, lo, hi = ctx.w, ctx.lo, ctx.hi
-        slot = getattr(w, "_vmc_grad", None)
-        if slot is not None:
-            slot[lo:hi].copy_(g.view(slot[lo:hi].shape))
-            return None, None, None
-        full = torch.zeros_like(w)
-        full[lo:hi].copy_(g.view(full[lo:hi].shape))
-        return full, None, None
 
 
 class _SelfAttn(torch.autograd.Function):

@@ -79,10 +79,15 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ res).  x [M,Kx] 16-bit (Kx = K or K padded to 64), W [N,K...] f32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, act, out_f32):
+    def forward(ctx, x, weight, bias, res, act, out_f32, rows=None):
+        """rows = (lo, hi): use only parameter rows [lo, hi) (the q / kv thirds of a packed in_proj, as
+        F.multi_head_attention_forward's _in_projection_packed does) -- sliced from the cached 16-bit copy."""
         dt16 = x.dtype
         K = weight[0].numel()
+        ctx.rows = rows
         w16 = weights.get(weight, dt16, pad_k=(K % 64 != 0))
+        if rows is not None:
+            w16 = w16[rows[0]:rows[1]]
         ctx.x_cols = x.shape[1]
         if w16.shape[1] != x.shape[1]:
             if x.shape[1] != K:
@@ -91,6 +96,8 @@ class LinearFn(torch.autograd.Function):
             xp[:, :K].copy_(x)
             x = xp
         b = bias.detach() if bias is not None else None
+        if b is not None and rows is not None:
+            b = b[rows[0]:rows[1]]
         z = None
         if act != ACT_NONE:
             if res is not None:
@@ -113,7 +120,9 @@ class LinearFn(torch.autograd.Function):
         weight, bias, act = ctx.weight, ctx.bias, ctx.act
         dt16 = x.dtype
         M = x.shape[0]
-        N = weight.shape[0]
+        rows = ctx.rows
+        lo, hi = rows if rows is not None else (0, weight.shape[0])
+        N = hi - lo
         K = weight[0].numel()
         dy = dy.contiguous()
         dy16 = ops.cast16(dy, dt16)
@@ -124,7 +133,9 @@ class LinearFn(torch.autograd.Function):
         # ---- dgrad: dx = dz @ W  (contraction over N; pad N to a multiple of 64 with zeros) ----
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = weights.get(weight, dt16, transposed=True, pad_k=(N % 64 != 0))      # [K, Npad]
+            wt = weights.get(weight, dt16, transposed=True, pad_k=(weight.shape[0] % 64 != 0))      # [K, Npad]
+            if rows is not None:
+                wt = wt[:, lo:hi]                                                      # K-contiguous column window
             dzp = dz
             if wt.shape[1] != N:
                 dzp = torch.zeros((M, wt.shape[1]), dtype=dt16, device=dz.device)
@@ -144,20 +155,37 @@ class LinearFn(torch.autograd.Function):
             xt = torch.zeros((Kx, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((Kx, Mp), dtype=dt16, device=dz.device)
             check(lib.vmc_transpose16(ptr(x), ptr(xt), M, Kx, x.stride(0), Mp, stream()), "transpose16")
             if Kx == K and K % 4 == 0:
-                out = _grad_out(weight, (N, K))
-                ops.linear(dzt, xt, out=out.view(N, K))
-                dw = out
+                slot = getattr(weight, "_vmc_grad", None)
+                if rows is not None and slot is not None:
+                    ops.linear(dzt, xt, out=slot.view(weight.shape[0], K)[lo:hi])      # in place into the parameter's rows
+                    dw = slot
+                elif rows is not None:
+                    dw = torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
+                    ops.linear(dzt, xt, out=dw[lo:hi])
+                else:
+                    out = _grad_out(weight, (N, K))
+                    ops.linear(dzt, xt, out=out.view(N, K))
+                    dw = out
             else:
                 full = ops.linear(dzt, xt, out_dtype=torch.float32)                    # [N, Kx]
                 dw = full[:, :K].contiguous()
         db = None
         if bias is not None and bias.requires_grad:
             db = ops.colsum(dz)
-        return dx, _deliver(weight, dw), _deliver(bias, db), dres, None, None
+            if rows is not None:
+                slot = getattr(bias, "_vmc_grad", None)
+                if slot is not None:
+                    slot[lo:hi].copy_(db)
+                    db = slot
+                else:
+                    full = torch.zeros_like(bias)
+                    full[lo:hi].copy_(db)
+                    db = full
+        return dx, _deliver(weight, dw), _deliver(bias, db), dres, None, None, None
 
 
-def linear(x, weight, bias=None, res=None, act=ACT_NONE, out_f32=False):
-    return LinearFn.apply(x, weight, bias, res, act, out_f32)
+def linear(x, weight, bias=None, res=None, act=ACT_NONE, out_f32=False, rows=None):
+    return LinearFn.apply(x, weight, bias, res, act, out_f32, rows)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -207,6 +207,134 @@ extern "C" int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int
 }
 
 // ==================================================================================================
+// Short-sequence masked attention on MFMA (TFAM self / cross attention: T = 16..64 tokens, head_dim 64 or 96).
+// One wave per (batch, head): K and V of the head (<= 64 keys) in LDS, same S^T = K Q^T / O^T = V^T P^T
+// formulation as the ViT kernel; key-padding mask -> -inf before the softmax.  Rows are padded by 16 B instead
+// of XOR-swizzled (tiles of a few KB: bank conflicts are irrelevant, launch count is what matters here).
+// ==================================================================================================
+template <typename T, int DH, int NT>
+__global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                        const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
+                                                        uint16_t* __restrict__ op, float* __restrict__ lse, int H, int Tq, int Tk,
+                                                        int ldq, int ldk, int ldv, int ldo, float scale) {
+  constexpr int NKEYS = 16 * NT, CH = DH / 8, RS = DH * 2 + 16, KK = DH / 32, DT = DH / 16;
+  __shared__ __attribute__((aligned(16))) char k_lds[NKEYS * RS];
+  __shared__ __attribute__((aligned(16))) char v_lds[NKEYS * RS];
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const uint16_t* kb = kp + (size_t)b * Tk * ldk + h * DH;
+  const uint16_t* vb = vp + (size_t)b * Tk * ldv + h * DH;
+  {
+    constexpr int ITERS = (NKEYS * CH + 63) / 64;
+    uint4 kreg[ITERS], vreg[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
+      kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
+      if (idx < NKEYS * CH && row < Tk) {
+        kreg[i] = *(const uint4*)(kb + (size_t)row * ldk + c * 8);
+        vreg[i] = *(const uint4*)(vb + (size_t)row * ldv + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
+      if (idx < NKEYS * CH) {
+        *(uint4*)(k_lds + row * RS + c * 16) = kreg[i];
+        *(uint4*)(v_lds + row * RS + c * 16) = vreg[i];
+      }
+    }
+  }
+  // which of this lane's keys (16 nt + 4 q + j) may be attended
+  bool live[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = 16 * nt + 4 * q + j;
+      live[nt][j] = key < Tk && (mask == nullptr || mask[(size_t)b * Tk + key] != 0);
+    }
+  __syncthreads();
+
+  const float c2 = scale * 1.4426950408889634f;
+  const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
+  for (int qt = 0; qt * 16 < Tq; ++qt) {
+    const int qrow = qt * 16 + r;
+    const uint16_t* qr = qp + ((size_t)b * Tq + min(qrow, Tq - 1)) * ldq + h * DH;
+    uint4 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const uint4*)(qr + (4 * kk + q) * 8);
+    f32x4 s[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        s[nt] = T::mfma16(*(const uint4*)(k_lds + (16 * nt + r) * RS + (4 * kk + q) * 16), qf[kk], s[nt]);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!live[nt][j]) s[nt][j] = -INFINITY;
+        m = fmaxf(m, s[nt][j]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c2;   // a fully masked row gives exp2(NaN): NaN output, as torch
+    f32x4 o[DT], osum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NT / 2; ++ks) {
+      const f32x4 a = s[2 * ks], bb = s[2 * ks + 1];
+      uint4 pf;
+      pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[1], c2, -mc)));
+      pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[3], c2, -mc)));
+      pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(bb[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(bb[1], c2, -mc)));
+      pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(bb[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(bb[3], c2, -mc)));
+      osum = T::mfma16(ones, pf, osum);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        // transposed 4-key x 16-column blocks: this lane supplies key row 32 ks + 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
+        const char* p0 = v_lds + (32 * ks + 4 * q + (r >> 2)) * RS + (16 * dt + 4 * (r & 3)) * 2;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0);
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(p0 + 16 * RS));
+        uint4 vf;
+        const uint2 x0 = __builtin_bit_cast(uint2, v0), x1 = __builtin_bit_cast(uint2, v1);
+        vf.x = x0.x; vf.y = x0.y; vf.z = x1.x; vf.w = x1.y;
+        o[dt] = T::mfma16(vf, pf, o[dt]);
+      }
+    }
+    const float sum = osum[0];
+    const float inv = 1.0f / sum;
+    if (qrow < Tq) {
+      uint16_t* orow = op + ((size_t)b * Tq + qrow) * ldo + h * DH + 4 * q;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *(uint2*)(orow + 16 * dt) = make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
+      if (lse != nullptr && q == 0) lse[((size_t)b * H + h) * Tq + qrow] = m * scale + __logf(sum);
+    }
+  }
+}
+
+template <typename T>
+static int launch_small(const void* q, const void* k, const void* v, const uint8_t* mask, void* out, float* lse, int B, int H, int Tq,
+                        int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+#define VMC_SMALL(DHV, NTV)                                                                                                      \
+  hipLaunchKernelGGL((attn_small_kernel<T, DHV, NTV>), dim3(B * H), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,      \
+                     (const uint16_t*)v, mask, (uint16_t*)out, lse, H, Tq, Tk, ldq, ldk, ldv, ldo, scale)
+  if (dh == 64 && Tk <= 32) VMC_SMALL(64, 2);
+  else if (dh == 64) VMC_SMALL(64, 4);
+  else if (dh == 96 && Tk <= 32) VMC_SMALL(96, 2);
+  else VMC_SMALL(96, 4);
+#undef VMC_SMALL
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ==================================================================================================
 // Generic masked attention, fp32 math.  One wave per (batch, head, query).  Scores live in LDS.
 // ==================================================================================================
 #define ATT_MAX_TK 2048
@@ -375,6 +503,11 @@ extern "C" int vmc_attention_fwd(const void* q, const void* k, const void* v, co
   if (rc) return rc;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return VMC_E_ALIGN;
   const float scale = 1.0f / sqrtf((float)dh);
+  if (dropout_p == 0.f && Tk <= 64 && (dh == 64 || dh == 96) && (ldo % 4) == 0) {   // short sequences: MFMA kernel, one wave per (b, h)
+    if (dtype16 == VMC_BF16) return launch_small<BF16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    if (dtype16 == VMC_F16) return launch_small<F16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    return VMC_E_DTYPE;
+  }
   dim3 grid(B * H * Tq);
   if (dtype16 == VMC_BF16)
     hipLaunchKernelGGL(attn_generic_fwd<BF16>, grid, dim3(64), 0, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k,

@@ -212,14 +212,27 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const void* __restr
     for (int r = r0; r < r1; ++r) a += T::to_f32(((const uint16_t*)in)[(size_t)r * ld + col]);
   partial[(size_t)blockIdx.y * N + col] = a;
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
-  float a = 0.f;
-  for (int s = 0; s < slabs; ++s) a += partial[(size_t)s * N + col];
-  out[col] = a;
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int W) {
+  __shared__ float sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < W) {
+    int p = ty;
+    for (; p + 12 < P; p += 16) {   // four independent loads in flight
+      a0 += partial[(size_t)p * W + col];
+      a1 += partial[(size_t)(p + 4) * W + col];
+      a2 += partial[(size_t)(p + 8) * W + col];
+      a3 += partial[(size_t)(p + 12) * W + col];
+    }
+    for (; p < P; p += 4) a0 += partial[(size_t)p * W + col];
+  }
+  sm[ty][tx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ty == 0 && col < W) out[col] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
-static int colsum_slabs(int M) { return M < COLSUM_SLABS * 4 ? (M + 3) / 4 : COLSUM_SLABS; }
+// enough slabs to fill the chip (N/256 column blocks x slabs), few enough that the second pass stays short
+static int colsum_slabs(int M) { int s = M / 128; return s < 1 ? 1 : (s > 64 ? 64 : s); }
 extern "C" size_t vmc_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_slabs(M) * N * sizeof(float); }
 extern "C" int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype, void* workspace, size_t workspace_bytes,
                           void* stream) {
@@ -233,7 +246,7 @@ extern "C" int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, i
   else
     hipLaunchKernelGGL(colsum_partial_kernel<BF16>, grid, dim3(256), 0, s, in, (float*)workspace, M, N, (size_t)ld_in, in_dtype == VMC_F32);
   VMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, slabs, N);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, s, (const float*)workspace, out, slabs, N);
   VMC_CHECK_LAUNCH();
   return 0;
 }

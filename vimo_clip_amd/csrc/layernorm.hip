@@ -258,14 +258,23 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-__global__ void ln_bwd_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                              int nblocks, int D) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  const int which = i / D, col = i % D;
-  float a = 0.f;
-  for (int b = 0; b < nblocks; ++b) a += partial[((size_t)b * 2 + which) * D + col];
-  (which ? dbeta : dgamma)[col] = a;
+__global__ void __launch_bounds__(256) ln_reduce_strided_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int P, int D) {
+  __shared__ float sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, which = blockIdx.y;
+  const int col = blockIdx.x * 64 + tx;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < D) {
+    int p = ty;
+    for (; p + 4 < P; p += 8) {
+      a0 += partial[((size_t)p * 2 + which) * D + col];
+      a1 += partial[((size_t)(p + 4) * 2 + which) * D + col];
+    }
+    for (; p < P; p += 4) a0 += partial[((size_t)p * 2 + which) * D + col];
+  }
+  sm[ty][tx] = a0 + a1;
+  __syncthreads();
+  if (ty == 0 && col < D) (which ? dbeta : dgamma)[col] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 
 static int ln_bwd_grid(int rows) { return grid_for((size_t)rows, 4, LN_BWD_BLOCKS); }
@@ -293,7 +302,7 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
   else
     return VMC_E_DTYPE;
   VMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 255) / 256), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
+  hipLaunchKernelGGL(ln_reduce_strided_kernel, dim3((D + 63) / 64, 2), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
   VMC_CHECK_LAUNCH();
   return 0;
 }
