@@ -75,6 +75,17 @@ def tfam_extras(dev, rank, world, cdt):
             t = _time_cuda(lambda: m(rgb, mot, mask_rgb=mk, mask_flow=mk), 20 if B <= 512 else 5)
         out[f"tfam_fwd_clips_per_s_B{B}"] = round(B / t, 1)
         out[f"tfam_fwd_mfma_frac_B{B}"] = round(B / t * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)
+        if B == 8:   # the reference's batch size: launch-bound, so also as ONE hipGraph replay per forward
+            from vimo_clip_amd.graphs import GraphedCallable
+
+            def fwd(r, f, a, b):
+                with torch.no_grad():
+                    return m(r, f, mask_rgb=a, mask_flow=b)
+            g = GraphedCallable(fwd, rgb, mot, mk, mk)
+            t = _time_cuda(g.replay, 50)
+            out["tfam_fwd_clips_per_s_B8_hipgraph"] = round(B / t, 1)
+            # HBM roofline of the small-batch forward: bf16 weights 63.7 MB + 98 KB/clip of fp32 tokens
+            out["tfam_fwd_hbm_frac_B8_hipgraph"] = round((63.7e6 + B * 98304) / t / 8e12, 4)
     # ---- train step, per-GPU batch 512 (weak scaling), AdamW lr 1e-4 wd 0.1 as TFAM/train_and_eval.py:53 ----
     B = 512
     m.train()

@@ -114,6 +114,11 @@ int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
  * ln_post (OpenAI clip ResidualAttentionBlock.forward).  D % 256 == 0, D <= 2048. */
 int vmc_add_layernorm_fwd(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows,
                           int D, int ldx, int ldb, float eps, int write_x, int dtype16, void* stream);
+/* Post-norm block tail of the TFAM AttentionLayer (TFAM/models/AMO_CLIP.py:40,45,50: norm(x + dropout(branch))):
+ * s = x (f32 [rows,D]) + branch (16-bit [rows,D]); y = LN(s) written as f32 (y32, next residual operand) and/or 16-bit
+ * (y16, next GEMM operand); optional saves for the backward: sum_out = s, mean, rstd.  D % 256 == 0, D <= 2048. */
+int vmc_postnorm_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
+                     void* y16, float* mean, float* rstd, int rows, int D, float eps, int dtype16, void* stream);
 /* Backward (autograd of the LayerNorms, train.py:104): dx [rows,D] (f32 or 16-bit per dx_dtype) =
  * LN'(dy) + add, where `add` (optional, dx's dtype/layout) is the gradient arriving over the residual
  * branch that forks at x (fused so the fork needs no separate add pass).  dgamma/dbeta f32 [D],

@@ -69,38 +69,37 @@ class AttentionLayer(nn.Module):
         self.p = dropout
         self.d_model, self.num_heads = d_model, num_heads
 
-    # x32: fp32 [B*T, D] tokens (residual operand); returns the next fp32 token matrix
-    def run(self, x32, B, T, dt16, mask_u8, cross16=None, Tk=0, cross_mask_u8=None, seed_fn=None):
+    # x32 / x16: the token matrix [B*T, D] as fp32 (residual operand) and in the compute dtype (GEMM operand)
+    def run(self, x32, x16, B, T, dt16, mask_u8, cross16=None, Tk=0, cross_mask_u8=None, seed_fn=None):
         H, D = self.num_heads, self.d_model
         tr = self.training
         p = self.p if tr else 0.0
-        xr, xg = ag.fork(x32, dt16)
-        x16 = ag.cast(xg, dt16)
+        fused = D % 256 == 0 and D <= 2048
+
+        def tail(xr, branch, norm):           # LN(x + dropout(branch)) -> (fp32, 16-bit)
+            branch = ag.dropout(branch, p, tr, seed_fn)
+            if fused:
+                return ag.postnorm(xr, branch, norm.weight, norm.bias)
+            y = ag.layernorm(_add32(xr, branch, dt16), norm.weight, norm.bias, dt16, out_f32=True)
+            a, b2 = ag.fork(y, dt16)
+            return a, ag.cast(b2, dt16)
+
         qkv = ag.linear(x16, self.self_attn.in_proj_weight, self.self_attn.in_proj_bias)
         o = _SelfAttn.apply(qkv, mask_u8, B, T, H, p, seed_fn() if p > 0 else 0)
         o = ag.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias)
-        o = ag.dropout(o, p, tr, seed_fn)
-        y = _add32(xr, o, dt16)
-        x32 = ag.layernorm(y, self.norm_self.weight, self.norm_self.bias, dt16, out_f32=True)
+        x32, x16 = tail(x32, o, self.norm_self)
         if cross16 is not None:
-            xr, xg = ag.fork(x32, dt16)
-            x16 = ag.cast(xg, dt16)
             W, b = self.cross_attn.in_proj_weight, self.cross_attn.in_proj_bias
             q = ag.linear(x16, W, b, rows=(0, D))              # _in_projection_packed: q from rows 0:D,
             kv = ag.linear(cross16, W, b, rows=(D, 3 * D))      # k | v from rows D:3D of the packed in_proj
             o = _CrossAttn.apply(q, kv, cross_mask_u8, B, T, Tk, H, p, seed_fn() if p > 0 else 0)
             o = ag.linear(o, self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias)
-            o = ag.dropout(o, p, tr, seed_fn)
-            y = _add32(xr, o, dt16)
-            x32 = ag.layernorm(y, self.norm_cross.weight, self.norm_cross.bias, dt16, out_f32=True)
-        xr, xg = ag.fork(x32, dt16)
-        x16 = ag.cast(xg, dt16)
+            x32, x16 = tail(x32, o, self.norm_cross)
         h = ag.linear(x16, self.ffn[0].weight, self.ffn[0].bias, act=self.ffn_act)
         h = ag.dropout(h, p, tr, seed_fn)
         f = ag.linear(h, self.ffn[3].weight, self.ffn[3].bias)
-        f = ag.dropout(ag.dropout(f, p, tr, seed_fn), p, tr, seed_fn)     # ffn's own Dropout, then self.dropout (:28,:50)
-        y = _add32(xr, f, dt16)
-        return ag.layernorm(y, self.norm_ffn.weight, self.norm_ffn.bias, dt16, out_f32=True)
+        f = ag.dropout(f, p, tr, seed_fn)                                  # ffn's own trailing Dropout (:28); self.dropout (:50) is in tail()
+        return tail(x32, f, self.norm_ffn)
 
 
 class _Add32(torch.autograd.Function):
@@ -227,19 +226,23 @@ class AMO_CLIP(nn.Module):
         def flat(t):
             return t.contiguous().float().view(-1, t.shape[-1])
 
+        def pair(x32):
+            a, b2 = ag.fork(x32, dt16)
+            return a, ag.cast(b2, dt16)
+
         if self.use_only_rgb:
-            x, T, m = flat(rgb_emb), rgb_emb.shape[1], m_rgb
+            (x, x16), T, m = pair(flat(rgb_emb)), rgb_emb.shape[1], m_rgb
             for layer in self.layers:
-                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+                x, x16 = layer.run(x, x16, B, T, dt16, m, seed_fn=seed_fn)
         elif self.use_only_flow:
-            x, T, m = flat(motion_emb), motion_emb.shape[1], m_flow
+            (x, x16), T, m = pair(flat(motion_emb)), motion_emb.shape[1], m_flow
             for layer in self.layers:
-                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+                x, x16 = layer.run(x, x16, B, T, dt16, m, seed_fn=seed_fn)
         elif self.use_cross_attention:
-            x, T, Tk = flat(rgb_emb), rgb_emb.shape[1], motion_emb.shape[1]
+            (x, x16), T, Tk = pair(flat(rgb_emb)), rgb_emb.shape[1], motion_emb.shape[1]
             cross16 = ag.cast(flat(motion_emb), dt16)
             for layer in self.layers:
-                x = layer.run(x, B, T, dt16, m_rgb, cross16=cross16, Tk=Tk, cross_mask_u8=m_flow, seed_fn=seed_fn)
+                x, x16 = layer.run(x, x16, B, T, dt16, m_rgb, cross16=cross16, Tk=Tk, cross_mask_u8=m_flow, seed_fn=seed_fn)
         else:
             rgb_cut = rgb_emb[:, :-1, :]
             m_cut = m_rgb[:, :-1] if m_rgb is not None else None
@@ -252,8 +255,9 @@ class AMO_CLIP(nn.Module):
                 T = xcat.shape[1]
                 x = ag.linear(ag.cast(flat(xcat), dt16), self.projection_layer.weight, self.projection_layer.bias, out_f32=True)
                 m = m_flow
+            x, x16 = pair(x)
             for layer in self.layers:
-                x = layer.run(x, B, T, dt16, m, seed_fn=seed_fn)
+                x, x16 = layer.run(x, x16, B, T, dt16, m, seed_fn=seed_fn)
         pooled = ag.MeanPoolFn.apply(x, B, T, dt16, True)                                      # [B, D] f32, all T rows
         h = ag.layernorm(pooled, self.classifier[0].weight, self.classifier[0].bias, dt16)
         h = ag.linear(h, self.classifier[1].weight, self.classifier[1].bias, act=ops.ACT_GELU_ERF)

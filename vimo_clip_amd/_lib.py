@@ -33,6 +33,7 @@ SIGNATURES = {
     "vmc_colsum": (I, [P, P, I, I, I, I, P, Z, P]),
     "vmc_layernorm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "vmc_add_layernorm_fwd": (I, [P, P, P, P, P, I, I, I, I, F, I, I, P]),
+    "vmc_postnorm_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, F, I, P]),
     "vmc_layernorm_bwd_workspace_bytes": (Z, [I, I]),
     "vmc_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "vmc_scale_by_device_scalar": (I, [P, P, Z, P, P]),

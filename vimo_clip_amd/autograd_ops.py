@@ -79,7 +79,7 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ res).  x [M,Kx] 16-bit (Kx = K or K padded to 64), W [N,K...] f32 parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, act, out_f32, rows=None):
+    def forward(ctx, x, weight, bias, res, act, out_f32, rows=None, inference=False):
         """rows = (lo, hi): use only parameter rows [lo, hi) (the q / kv thirds of a packed in_proj, as
         F.multi_head_attention_forward's _in_projection_packed does) -- sliced from the cached 16-bit copy."""
         dt16 = x.dtype
@@ -102,6 +102,8 @@ class LinearFn(torch.autograd.Function):
         if act != ACT_NONE:
             if res is not None:
                 raise ValueError("LinearFn: activation and residual are not combined on this path")
+            if inference:                          # no graph is being built: activation fused into the GEMM epilogue
+                return ops.linear(x, w16, bias=b, act=act, out_dtype=torch.float32 if out_f32 else dt16)
             z = ops.linear(x, w16, bias=b)
             y = ops.act_fwd(z, act)
             if out_f32:
@@ -181,11 +183,12 @@ class LinearFn(torch.autograd.Function):
                     full = torch.zeros_like(bias)
                     full[lo:hi].copy_(db)
                     db = full
-        return dx, _deliver(weight, dw), _deliver(bias, db), dres, None, None, None
+        return dx, _deliver(weight, dw), _deliver(bias, db), dres, None, None, None, None
 
 
 def linear(x, weight, bias=None, res=None, act=ACT_NONE, out_f32=False, rows=None):
-    return LinearFn.apply(x, weight, bias, res, act, out_f32, rows)
+    # (grad mode is always off INSIDE Function.forward, so it is sampled here)
+    return LinearFn.apply(x, weight, bias, res, act, out_f32, rows, not torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -225,6 +228,50 @@ class LayerNormFn(torch.autograd.Function):
         check(lib.vmc_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma.detach()), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dg), ptr(db),
                                     rows, D, D, dt(dy), dt(x), dt(dx), dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
         return dx, _deliver(gamma, dg), _deliver(beta, db), None, None, None
+
+
+class PostNormFn(torch.autograd.Function):
+    """(y32, y16) = LN(x32 + branch16): the tail of a post-norm block in one kernel (vmc_postnorm_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x32, branch, gamma, beta, need):
+        D = gamma.shape[0]
+        rows = x32.numel() // D
+        dev = x32.device
+        y32 = torch.empty((rows, D), dtype=torch.float32, device=dev)
+        y16 = torch.empty((rows, D), dtype=branch.dtype, device=dev)
+        ssum = torch.empty((rows, D), dtype=torch.float32, device=dev) if need else None
+        mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        check(lib.vmc_postnorm_fwd(ptr(x32), ptr(branch), ptr(gamma.detach()), ptr(beta.detach()), ptr(ssum), ptr(y32), ptr(y16),
+                                   ptr(mean), ptr(rstd), rows, D, 1e-5, dt(branch), stream()), "postnorm_fwd")
+        ctx.save_for_backward(ssum, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.dt16 = gamma, beta, branch.dtype
+        return y32, y16
+
+    @staticmethod
+    def backward(ctx, dy32, dy16):
+        ssum, mean, rstd = ctx.saved_tensors
+        gamma, beta, dt16 = ctx.gamma, ctx.beta, ctx.dt16
+        D = gamma.shape[0]
+        rows = ssum.numel() // D
+        if dy32 is None:
+            dy = dy16.contiguous()
+        elif dy16 is None:
+            dy = dy32.contiguous()
+        else:
+            dy = _add(dy32.contiguous(), dy16.contiguous(), torch.float32, dt16)
+        dsum = torch.empty_like(ssum)
+        dg, db = _grad_out(gamma, (D,)), _grad_out(beta, (D,))
+        nbytes = lib.vmc_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=ssum.device)
+        check(lib.vmc_layernorm_bwd(ptr(dy), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
+                                    rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
+        return dsum, ops.cast16(dsum, dt16), _deliver(gamma, dg), _deliver(beta, db), None
+
+
+def postnorm(x32, branch, gamma, beta):
+    return PostNormFn.apply(x32, branch, gamma, beta, torch.is_grad_enabled())
 
 
 def layernorm(x, gamma, beta, dt16, passthrough=False, out_f32=False):

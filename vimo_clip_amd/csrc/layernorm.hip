@@ -179,6 +179,95 @@ extern "C" int vmc_add_layernorm_fwd(float* x, const void* branch, const float* 
   return VMC_E_DTYPE;
 }
 
+// ---- post-norm block tail: s = x + branch; y = LN(s) written as fp32 (next residual operand) and 16-bit (next GEMM
+// operand) in one pass (TFAM AttentionLayer: norm_self / norm_cross / norm_ffn, AMO_CLIP.py:40,45,50) ----------------
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) postnorm_kernel(const float* __restrict__ x, const uint16_t* __restrict__ branch,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ sum_out, float* __restrict__ y32, uint16_t* __restrict__ y16,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, float eps) {
+  constexpr int D = CH * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  float4 g[CH], b[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    g[c] = *(const float4*)(gamma + c * 256 + lane * 4);
+    b[c] = *(const float4*)(beta + c * 256 + lane * 4);
+  }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    float4 v[CH];
+    uint2 br[CH];
+    const size_t base = (size_t)row * D + lane * 4;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      v[c] = *(const float4*)(x + base + c * 256);
+      br[c] = *(const uint2*)(branch + base + c * 256);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float a0, a1, a2, a3;
+      unpack2<T>(br[c].x, a0, a1);
+      unpack2<T>(br[c].y, a2, a3);
+      v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      if (sum_out) *(float4*)(sum_out + base + c * 256) = v[c];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float p = v[c].x - mean, q = v[c].y - mean, r = v[c].z - mean, t = v[c].w - mean;
+      ss += (p * p + q * q) + (r * r + t * t);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * (1.0f / D) + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float4 o;
+      o.x = (v[c].x - mean) * rstd * g[c].x + b[c].x; o.y = (v[c].y - mean) * rstd * g[c].y + b[c].y;
+      o.z = (v[c].z - mean) * rstd * g[c].z + b[c].z; o.w = (v[c].w - mean) * rstd * g[c].w + b[c].w;
+      if (y32) *(float4*)(y32 + base + c * 256) = o;
+      if (y16) *(uint2*)(y16 + base + c * 256) = make_uint2(pack2<T>(o.x, o.y), pack2<T>(o.z, o.w));
+    }
+  }
+}
+
+template <typename T>
+static int launch_postnorm(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
+                           void* y16, float* mean, float* rstd, int rows, int D, float eps, hipStream_t s) {
+  const int grid = grid_for((size_t)rows, 4, 256 * 8);
+#define VMC_PN(CHN)                                                                                                          \
+  hipLaunchKernelGGL((postnorm_kernel<T, CHN>), dim3(grid), dim3(256), 0, s, x, (const uint16_t*)branch, gamma, beta, sum_out, y32, \
+                     (uint16_t*)y16, mean, rstd, rows, eps)
+  switch (D / 256) {
+    case 1: VMC_PN(1); break;
+    case 2: VMC_PN(2); break;
+    case 3: VMC_PN(3); break;
+    case 4: VMC_PN(4); break;
+    case 6: VMC_PN(6); break;
+    case 8: VMC_PN(8); break;
+    default: return VMC_E_SHAPE;
+  }
+#undef VMC_PN
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vmc_postnorm_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
+                                void* y16, float* mean, float* rstd, int rows, int D, float eps, int dtype16, void* stream) {
+  if (!x || !branch || !gamma || !beta || (!y32 && !y16) || rows <= 0 || D <= 0) return VMC_E_ARG;
+  if (D % 256 || D > 2048) return VMC_E_SHAPE;
+  if (dtype16 == VMC_BF16) return launch_postnorm<BF16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return launch_postnorm<F16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
 // ---- backward ---------------------------------------------------------------------------------
 // dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));  dgamma = sum_rows g*xhat;  dbeta = sum_rows g.
 // Each wave accumulates its rows' dgamma/dbeta partials in registers, then one partial row per block
