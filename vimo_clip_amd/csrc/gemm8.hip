@@ -224,55 +224,58 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
 
 
 // ==================================================================================================
-// Persistent variant: 256 workgroups (one per CU) walk the tile list of their XCD; the LDS-DMA pipeline
-// runs straight through tile boundaries (the last phases of tile j stage the first 1.5 K tiles of tile
-// j+1, exactly the prologue set, into the slots the schedule would use anyway), so the per-tile prologue
-// latency and the workgroup relaunch are gone and the epilogue stores overlap the next tile's loads.
-// Staging uses buffer_load ... lds: one descriptor per operand, per-lane offset in a VGPR, tile / half /
-// K offset in an SGPR; rows past M (or N) fall outside the descriptor and read as zeros.
+// Persistent variant (vmc_set_gemm_variant(2)): 256 workgroups (one per CU) walk the tile list of their XCD
+// group; the LDS-DMA pipeline runs straight through tile boundaries: the last K-tile pair of output tile j
+// stages the first 1.5 K tiles of tile j+1 (exactly the prologue set, into the slots the schedule would use
+// anyway), so the workgroup relaunch and the pipeline fill disappear and the epilogue stores overlap the next
+// tile's loads.  Same global_load_lds addressing as gemm8_kernel; the per-thread source pointers are switched
+// to the next tile in the middle of the roll-over iteration, right after the last current-tile stage.
+// (A first version staged through buffer_load ... lds with scalar offsets; its main loop measured 6-11 % slower.)
 // ==================================================================================================
-// The bounds check of a raw buffer access covers voffset (+ immediate) but, depending on the generation, not
-// soffset: the tile's ROW offset therefore travels in the VGPR offset (rows >= M or >= N then fall outside the
-// descriptor and read as zeros whichever way the hardware checks) and only the small K offset is scalar.
-__device__ __forceinline__ void g8p_stage(__amdgpu_buffer_rsrc_t rsrc, char* slot, const int (&voff)[2], int row_off, int k_off,
-                                          int wave_lds) {
+__device__ __forceinline__ void g8_set_ptrs(const GemmArgs& g, int tid, int m0, int n0, const char* (&sA0)[2], const char* (&sA1)[2],
+                                            const char* (&sB0)[2], const char* (&sB1)[2]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (VMC_LDS void*)(slot + i * 8192 + wave_lds), 16, voff[i] + row_off, k_off, 0, 0);
+  for (int i = 0; i < 2; ++i) {
+    int row, ch;
+    stage_src_x(i * 512 + tid, row, ch);
+    sA0[i] = g.A + ((size_t)min(m0 + row, g.M - 1) * g.lda + ch * 8) * 2;
+    sA1[i] = g.A + ((size_t)min(m0 + 128 + row, g.M - 1) * g.lda + ch * 8) * 2;
+    stage_src_w8(i * 512 + tid, row, ch);
+    sB0[i] = g.W + ((size_t)min(n0 + row, g.N - 1) * g.ldw + ch * 8) * 2;
+    sB1[i] = g.W + ((size_t)min(n0 + 128 + row, g.N - 1) * g.ldw + ch * 8) * 2;
+  }
 }
 
-struct G8Offs {   // per K tile t+1, t+2, t+3 (t+2, t+3 possibly in the next output tile): row byte offsets of the A / W
-  int ar1, br1, k1, ar2, br2, k2, ar3, br3, k3;   // tile and the K byte offset
-};
-
 template <typename T>
-__device__ __forceinline__ void g8p_iter(char* A0e, char* A1e, char* B0e, char* B1e, char* A0o, char* A1o, char* B0o, char* B1o,
-                                         __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, const int (&va)[2], const int (&vb)[2],
-                                         const G8Offs o, int HA, int HB, int wave_lds, const int (&xoff)[2],
-                                         const int (&woff)[2][2], f32x4 (&acc)[2][2][4][2], G8Frags<T>& f, int ns) {
+__device__ __forceinline__ void g8q_iter(char* A0e, char* A1e, char* B0e, char* B1e, char* A0o, char* A1o, char* B0o, char* B1o,
+                                         const char* (&sA0)[2], const char* (&sA1)[2], const char* (&sB0)[2], const char* (&sB1)[2],
+                                         size_t k1, size_t k2, size_t k3, int wave_lds, const int (&xoff)[2], const int (&woff)[2][2],
+                                         f32x4 (&acc)[2][2][4][2], G8Frags<T>& f, int ns, bool roll, const GemmArgs& g, int tid, int nm0,
+                                         int nn0) {
   // ---- even tile ----
   g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
-  g8p_stage(rb, B1o, vb, o.br1 + HB, o.k1, wave_lds); g8_wait8_plus(ns);
+  g8_stage(B1o, sB1, k1, wave_lds); g8_wait8_plus(ns);
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1e, woff, f.b1);
-  g8p_stage(ra, A1o, va, o.ar1 + HA, o.k1, wave_lds); g8_wait8_plus(ns);
+  g8_stage(A1o, sA1, k1, wave_lds); g8_wait8_plus(ns);
+  if (roll) g8_set_ptrs(g, tid, nm0, nn0, sA0, sA1, sB0, sB1);   // everything staged from here on belongs to the next output tile
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1e, xoff, f.a);
-  g8p_stage(ra, A0e, va, o.ar2, o.k2, wave_lds);
+  g8_stage(A0e, sA0, k2, wave_lds);
   g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8p_stage(rb, B0e, vb, o.br2, o.k2, wave_lds); g8_wait8_plus(ns);
+  g8_stage(B0e, sB0, k2, wave_lds); g8_wait8_plus(ns);
   g8_mma<T>(acc[1][0], f.a, f.b0);
   // ---- odd tile ----
   g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
-  g8p_stage(rb, B1e, vb, o.br2 + HB, o.k2, wave_lds); G8_WAIT8();
+  g8_stage(B1e, sB1, k2, wave_lds); G8_WAIT8();
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1o, woff, f.b1);
-  g8p_stage(ra, A1e, va, o.ar2 + HA, o.k2, wave_lds); G8_WAIT8();
+  g8_stage(A1e, sA1, k2, wave_lds); G8_WAIT8();
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1o, xoff, f.a);
-  g8p_stage(ra, A0o, va, o.ar3, o.k3, wave_lds);
+  g8_stage(A0o, sA0, k3, wave_lds);
   g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8p_stage(rb, B0o, vb, o.br3, o.k3, wave_lds); G8_WAIT8();
+  g8_stage(B0o, sB0, k3, wave_lds); G8_WAIT8();
   g8_mma<T>(acc[1][0], f.a, f.b0);
 }
 
@@ -300,26 +303,14 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
 
-  // this workgroup's tile list: ids first + 32*j inside the contiguous range of its XCD group
+  // this workgroup's tile list: ids first + per*j inside the contiguous range of its XCD group
   const int ntiles = g.tiles_m * g.tiles_n;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
   const int tq = ntiles >> 3, tr = ntiles & 7;
-  const int first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + slot;
-  const int end = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tq + (xcd < tr ? 1 : 0);
-  if (first >= end) return;   // (whole workgroup; never happens for ntiles >= gridDim.x)
+  const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int first = lo + slot, end = lo + tq + (xcd < tr ? 1 : 0);
+  if (first >= end) return;   // whole workgroup; never taken for ntiles >= gridDim.x
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
-  int va[2], vb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row, ch;
-    stage_src_x(i * 512 + tid, row, ch);
-    va[i] = (row * g.lda + ch * 8) * 2;
-    stage_src_w8(i * 512 + tid, row, ch);
-    vb[i] = (row * g.ldw + ch * 8) * 2;
-  }
-  const int HA = 128 * g.lda * 2, HB = 128 * g.ldw * 2;   // second half-tile (rows +128)
   const int wave_lds = wave * 1024;
   int xoff[2], woff[2][2];
 #pragma unroll
@@ -336,10 +327,11 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   const int nkt = g.K >> 6;  // even, >= 2
   int tm, tn;
   g8_tile_coords(g, first, tm, tn);
-  int abase = tm * 256 * g.lda * 2, bbase = tn * 256 * g.ldw * 2;
+  const char *sA0[2], *sA1[2], *sB0[2], *sB1[2];
+  g8_set_ptrs(g, tid, tm * 256, tn * 256, sA0, sA1, sB0, sB1);
   // prologue of the first tile (same issue order as the steady state)
-  g8p_stage(ra, A0e, va, abase, 0, wave_lds); g8p_stage(rb, B0e, vb, bbase, 0, wave_lds); g8p_stage(rb, B1e, vb, bbase + HB, 0, wave_lds);
-  g8p_stage(ra, A1e, va, abase + HA, 0, wave_lds); g8p_stage(ra, A0o, va, abase, 128, wave_lds); g8p_stage(rb, B0o, vb, bbase, 128, wave_lds);
+  g8_stage(A0e, sA0, 0, wave_lds); g8_stage(B0e, sB0, 0, wave_lds); g8_stage(B1e, sB1, 0, wave_lds);
+  g8_stage(A1e, sA1, 0, wave_lds); g8_stage(A0o, sA0, 128, wave_lds); g8_stage(B0o, sB0, 128, wave_lds);
   G8_WAIT8();
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
@@ -349,11 +341,9 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   int ns = 0;   // store instructions this wave issued in the previous tile's epilogue
   for (int tile = first; tile < end; tile += per) {
     const int m0 = tm * 256, n0 = tn * 256;
-    // next output tile (or this one again when the list ends: the tail prefetches stay in bounds and are never read)
     int ntm = tm, ntn = tn;
     const bool has_next = tile + per < end;
     if (has_next) g8_tile_coords(g, tile + per, ntm, ntn);
-    const int nabase = ntm * 256 * g.lda * 2, nbbase = ntn * 256 * g.ldw * 2;
 
     f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -366,20 +356,15 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
           for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < nkt; t += 2) {
-      G8Offs o;
-      // K tile t+1 always belongs to this output tile (nkt even); t+2 and t+3 roll over into the next one
-      o.ar1 = abase; o.br1 = bbase; o.k1 = (t + 1) * 128;
-      if (t + 2 < nkt) {
-        o.ar2 = o.ar3 = abase; o.br2 = o.br3 = bbase;
-        o.k2 = (t + 2) * 128; o.k3 = (t + 3) * 128;
-      } else if (has_next) {
-        o.ar2 = o.ar3 = nabase; o.br2 = o.br3 = nbbase;
-        o.k2 = 0; o.k3 = 128;
-      } else {
-        o.ar2 = o.ar3 = abase; o.br2 = o.br3 = bbase;
-        o.k2 = o.k3 = (nkt - 1) * 128;
-      }
-      g8p_iter<T>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, va, vb, o, HA, HB, wave_lds, xoff, woff, acc, f, t == 0 ? ns : 0);
+      const bool lastpair = t + 2 >= nkt;
+      const bool roll = lastpair && has_next;
+      // K tile t+1 belongs to this output tile (nkt even); t+2 / t+3 roll over into the next tile, or (no next tile)
+      // re-load this tile's last K tile into slots nobody reads again
+      const size_t k1 = (size_t)(t + 1) * 128;
+      const size_t k2 = lastpair ? (roll ? 0 : (size_t)(nkt - 1) * 128) : (size_t)(t + 2) * 128;
+      const size_t k3 = lastpair ? (roll ? 128 : (size_t)(nkt - 1) * 128) : (size_t)(t + 3) * 128;
+      g8q_iter<T>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, sA0, sA1, sB0, sB1, k1, k2, k3, wave_lds, xoff, woff, acc, f,
+                  t == 0 ? ns : 0, roll, g, tid, ntm * 256, ntn * 256);
     }
 
     // epilogue of this tile; the next tile's first K tiles are already in flight
@@ -412,7 +397,7 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
       }
       ns = __builtin_amdgcn_readfirstlane(rows_on * segs_on);
     }
-    tm = ntm; tn = ntn; abase = nabase; bbase = nbbase;
+    tm = ntm; tn = ntn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -456,8 +441,7 @@ template <typename T>
 static int g8_act(GemmArgs& g, int act, hipStream_t s) {
   // persistent kernel unless an operand does not fit a 2 GiB buffer descriptor (VMC_GEMM8=1 forces the
   // one-tile-per-workgroup kernel for A/B measurements)
-  const bool fits = (size_t)g.M * g.lda * 2 < (1ull << 31) && (size_t)g.N * g.ldw * 2 < (1ull << 31);
-  if (fits && vmc_gemm_variant() == 2) {
+  if (vmc_gemm_variant() == 2) {
     switch (act) {
       case VMC_ACT_NONE: return g8p_launch<T, VMC_ACT_NONE>(g, s);
       case VMC_ACT_QUICKGELU: return g8p_launch<T, VMC_ACT_QUICKGELU>(g, s);
