@@ -59,6 +59,16 @@ int vmc_preprocess_patches_u8(const uint8_t* frames, void* patches, int F, int R
 int vmc_patches_f32(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16,
                     void* stream);
 
+/* Pillow-exact antialiased resample of planar u8 images [planes, in_h, in_w] along one axis — the BICUBIC
+ * ``Resize`` of clip._transform (models/student_model.py:77-78) and of CLIPImageProcessor (extract_embeddings.py:91),
+ * both of which call PIL.Image.resize.  out pixel o (of the resampled axis) = clip8((2^21 + sum_t in[lo_o + t] *
+ * coeffs[o*ksize + t]) >> 22) with (lo_o, n_o) = bounds[2o], bounds[2o+1]; tables are Pillow's precompute_coeffs in
+ * 22-bit fixed point, computed by the host in float64.  Only outputs [out_first, out_first + out_count) are written
+ * (the centre crop is fused): horizontal -> out [planes, in_h, out_count], vertical -> out [planes, out_count, in_w].
+ * wrap_quirk applies v -> (256 - v) & 255 to the INPUT pixels (the student's float -> to_pil_image wrap). */
+int vmc_resample_u8(const uint8_t* in, uint8_t* out, const int* bounds, const int* coeffs, int planes, int in_h, int in_w,
+                    int out_first, int out_count, int ksize, int horizontal, int wrap_quirk, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K1/K3/K5/K6/K7/K9/K11-K14 — Linear layers:  C = epilogue(A @ W^T)   (MFMA, fp32 accumulate).
  * Replaces nn.Linear / F.linear / conv1-as-GEMM / `x @ proj` op sites: visual.conv1, attn.in_proj,

@@ -62,3 +62,35 @@ def test_encoder_chunking_and_batch_independence():
     m.frame_chunk = 3
     chunked = m.encode_frames_u8(u8)
     assert torch.equal(full, chunked)          # frames are independent: identical bits whatever the batch split
+
+
+@pytest.mark.parametrize("H,W", [(360, 640), (240, 320), (300, 300), (224, 400), (500, 375), (112, 150)])
+@pytest.mark.parametrize("mode", ["torchvision", "hf"])
+def test_gpu_resize_center_crop_is_pil_exact(H, W, mode):
+    """Resize(224, BICUBIC) + CenterCrop(224) on the GPU is bit-identical to PIL (run live here)."""
+    from PIL import Image
+
+    from oracle import pil_resize as opr
+    from vimo_clip_amd.preprocess import resize_center_crop_u8
+    fr = synth.randint_u8(9, f"fr{H}x{W}", (2, 3, H, W))
+    out, pending = resize_center_crop_u8(fr.cuda(), 224, mode, wrap_quirk=True)
+    assert not pending
+    src = ovit.to_pil_wrap_u8(fr).numpy()
+    nh, nw = opr.shortest_edge_size(H, W, 224)
+    top, left = opr.center_crop_offsets(nh, nw, 224, mode)
+    for f in range(2):
+        ref = np.asarray(Image.fromarray(np.transpose(src[f], (1, 2, 0))).resize((nw, nh), Image.BICUBIC))[top:top + 224, left:left + 224]
+        assert np.array_equal(np.transpose(out[f].cpu().numpy(), (1, 2, 0)), ref)
+
+
+def test_encoder_on_non_square_frames_vs_oracle():
+    # 360x640 frames (the Animal Kingdom flow videos) through the student's preprocessing incl. the wrap quirk
+    from oracle import pil_resize as opr
+    c = dict(model="ViT-B/32", seed=98, stress=1.0)
+    m = _encoder(c, torch.float16)
+    u8 = synth.randint_u8(98, "frames", (3, 3, 360, 640))
+    sd = synth.vit_state_dict(c["model"], c["seed"], c["stress"])
+    pre = torch.from_numpy(opr.clip_resize_crop(ovit.to_pil_wrap_u8(u8).numpy(), 224, "torchvision").copy())
+    ref = ovit.vit_forward(sd, ovit.normalize_u8(pre), 12)
+    y = m.encode_frames_u8(u8.cuda(), wrap_quirk=True).cpu()
+    assert (y - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())

@@ -25,6 +25,7 @@ SIGNATURES = {
     "vmc_error_string": (c_char_p, [I]),
     "vmc_preprocess_patches_u8": (I, [P, P, I, I, I, I, I, I, P]),
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
+    "vmc_resample_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
     "vmc_set_gemm_variant": (I, [I]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),

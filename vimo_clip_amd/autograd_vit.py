@@ -19,8 +19,11 @@ def vit_tokens_train(model, x: torch.Tensor, wrap_quirk: bool = False):
     g = model.input_resolution // model.patch_size
     N = g * g + 1
     with torch.no_grad():   # the input frames carry no gradient
-        patches = (ops.preprocess_patches_u8(x, model.patch_size, dt16, wrap_quirk) if x.dtype == torch.uint8
-                   else ops.patches_f32(x, model.patch_size, dt16))
+        if x.dtype == torch.uint8:
+            x, wrap_quirk = model.fit_frames_u8(x, wrap_quirk)
+            patches = ops.preprocess_patches_u8(x, model.patch_size, dt16, wrap_quirk)
+        else:
+            patches = ops.patches_f32(x, model.patch_size, dt16)
     xp = ag.linear(patches, model.conv1.weight)                                    # [F*g*g, D]
     xs = ag.AssembleTokensFn.apply(xp, model.class_embedding, model.positional_embedding, F, N, model.residual_dtype)
     xs = ag.layernorm(xs, model.ln_pre.weight, model.ln_pre.bias, dt16, out_f32=(model.residual_dtype == torch.float32))

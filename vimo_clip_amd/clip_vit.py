@@ -176,13 +176,22 @@ class VisionTransformer(nn.Module):
         y, *_ = ops.layernorm(x, ln.weight, ln.bias, self.compute_dtype)
         x.copy_(y)   # device-to-device copy (memory plumbing); only taken for a 16-bit residual stream
 
+    def fit_frames_u8(self, frames_u8: torch.Tensor, wrap_quirk: bool = False, crop_mode: str = "torchvision"):
+        """Frames of any size -> [F,3,R,R] u8 by Resize(R, BICUBIC) + CenterCrop(R) with Pillow's exact arithmetic
+        (preprocess.resize_center_crop_u8).  Returns (frames, wrap_still_pending)."""
+        R = self.input_resolution
+        if tuple(frames_u8.shape[-2:]) == (R, R):
+            return frames_u8, wrap_quirk
+        from .preprocess import resize_center_crop_u8
+        return resize_center_crop_u8(frames_u8, R, crop_mode, wrap_quirk)
+
     @torch.no_grad()
-    def encode_frames_u8(self, frames_u8: torch.Tensor, wrap_quirk: bool = False) -> torch.Tensor:
-        """[F,3,R,R] u8 -> [F,E] f32.  Fuses the CLIP normalisation into the patch extraction (K0)."""
+    def encode_frames_u8(self, frames_u8: torch.Tensor, wrap_quirk: bool = False, crop_mode: str = "torchvision") -> torch.Tensor:
+        """[F,3,H,W] u8 -> [F,E] f32.  Resize/crop (when H,W != R), CLIP normalisation and patch extraction run on the GPU (K0)."""
         outs = []
         for s in range(0, frames_u8.shape[0], self.frame_chunk):
-            fr = frames_u8[s:s + self.frame_chunk]
-            patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap_quirk)
+            fr, wrap = self.fit_frames_u8(frames_u8[s:s + self.frame_chunk], wrap_quirk, crop_mode)
+            patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap)
             outs.append(self._encode_patches(patches, fr.shape[0]))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 

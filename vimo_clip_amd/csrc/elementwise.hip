@@ -128,6 +128,46 @@ extern "C" int vmc_patches_f32(const float* pixel_values, void* patches, int F, 
   return 0;
 }
 
+// ---- Pillow-exact antialiased resample of planar u8 images along one axis (K0) --------------
+// out[p, i, j] = clip8((2^21 + sum_x in[...] * coeff[o, x]) >> 22), the fixed-point arithmetic of Pillow's
+// ImagingResample{Horizontal,Vertical}_8bpc; bounds/coeffs come from the host (float64, Pillow's precompute_coeffs).
+// Only the output range [out_first, out_first + out_count) is produced (centre crop fused).
+__global__ void __launch_bounds__(256) resample_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          const int* __restrict__ bounds, const int* __restrict__ coeffs, int planes,
+                                                          int in_h, int in_w, int out_first, int out_count, int ksize, int horizontal,
+                                                          int wrap) {
+  const int oh = horizontal ? in_h : out_count, ow = horizontal ? out_count : in_w;
+  const size_t total = (size_t)planes * oh * ow;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % ow), y = (int)((i / ow) % oh);
+    const size_t p = i / ((size_t)ow * oh);
+    const int o = out_first + (horizontal ? x : y);
+    const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = coeffs + (size_t)o * ksize;
+    const uint8_t* src = in + p * (size_t)in_h * in_w + (horizontal ? (size_t)y * in_w + lo : (size_t)lo * in_w + x);
+    const int step = horizontal ? 1 : in_w;
+    int acc = 1 << 21;
+    for (int t = 0; t < n; ++t) {
+      int v = src[(size_t)t * step];
+      if (wrap) v = (256 - v) & 255;
+      acc += v * k[t];
+    }
+    acc >>= 22;
+    out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+  }
+}
+
+extern "C" int vmc_resample_u8(const uint8_t* in, uint8_t* out, const int* bounds, const int* coeffs, int planes, int in_h, int in_w,
+                               int out_first, int out_count, int ksize, int horizontal, int wrap_quirk, void* stream) {
+  if (!in || !out || !bounds || !coeffs || planes <= 0 || in_h <= 0 || in_w <= 0 || out_count <= 0 || ksize <= 0 || out_first < 0)
+    return VMC_E_ARG;
+  const size_t total = (size_t)planes * (horizontal ? (size_t)in_h * out_count : (size_t)out_count * in_w);
+  hipLaunchKernelGGL(resample_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, bounds, coeffs, planes, in_h,
+                     in_w, out_first, out_count, ksize, horizontal, wrap_quirk);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- 16-bit transpose through a padded LDS tile --------------------------------------------------
 __global__ void __launch_bounds__(256) transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int rows,
                                                           int cols, size_t ld_in, size_t ld_out) {

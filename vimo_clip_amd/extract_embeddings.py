@@ -41,7 +41,7 @@ def encode_video_frames(encoder, frames_u8_nchw: torch.Tensor) -> np.ndarray:
     ``clip_model.get_image_features(pixel_values).cpu().numpy()`` (:94)."""
     vis = getattr(encoder, "visual", encoder)
     dev = next(vis.parameters()).device
-    return vis.encode_frames_u8(frames_u8_nchw.to(dev)).cpu().numpy()
+    return vis.encode_frames_u8(frames_u8_nchw.to(dev), crop_mode="hf").cpu().numpy()      # HF centre-crop rounding
 
 
 def create_hdf5_dataset(data_root, annotation_file, class_file, output_hdf5, max_frames=None, encoder=None,
@@ -75,10 +75,7 @@ def create_hdf5_dataset(data_root, annotation_file, class_file, output_hdf5, max
                 total = len(vr)
                 idx = sample_frame_indices(total, max_frames)
                 frames = frames_to_nchw(vr.get_batch(idx))
-                R = encoder.visual.input_resolution
-                if tuple(frames.shape[-2:]) != (R, R):
-                    raise NotImplementedError("PIL-exact resize/crop on the GPU is SURVEY.md §8f item 1")
-                emb = encode_video_frames(encoder, frames)
+                emb = encode_video_frames(encoder, frames)      # resize + centre crop + normalise + encode on the GPU
                 grp = hf.create_group(video_id)
                 grp.create_dataset("embeddings", data=emb, compression="gzip", chunks=(1, emb.shape[1]))
                 grp.create_dataset("labels", data=multi_hot([int(x) for x in info[1:]], num_classes))

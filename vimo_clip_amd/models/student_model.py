@@ -8,9 +8,10 @@ prefixed ``module.`` by DataParallel, train.py:167) load with ``strict=True``.
 Differences that are deliberate and documented:
   * there are no pretrained weights offline: ``clip.load(name)`` (:44) is replaced by building the
     named geometry with OpenAI-clip initialisation; load a checkpoint with ``load_state_dict``;
-  * the per-frame CPU loop ``to_pil_image -> CLIP preprocess`` (:77-78) runs as one HIP kernel fused
-    with patch extraction; its float->PIL wrap-around (v -> (256 - v) mod 256) is
-    reproduced bit-exactly for u8 / integer-valued inputs at the model resolution (H = W = 224).
+  * the per-frame CPU loop ``to_pil_image -> CLIP preprocess`` (:77-78) runs as HIP kernels: Pillow-exact
+    bicubic resize + centre crop (preprocess.py) when the frames are not already 224x224, then normalisation
+    fused with patch extraction; the float->PIL wrap-around (v -> (256 - v) mod 256) is
+    reproduced bit-exactly for u8 / integer-valued inputs.
 """
 from __future__ import annotations
 
@@ -86,12 +87,7 @@ class FlowStudentModel(nn.Module):
 
     def _frames_u8(self, flow_videos):
         B, T, C, H, W = flow_videos.shape
-        R = self.visual_encoder.input_resolution
-        if (H, W) != (R, R):
-            raise NotImplementedError(
-                f"frames are {H}x{W}; the HIP preprocess handles {R}x{R} input (PIL-exact bicubic resize + centre crop "
-                "is SURVEY.md §8f item 1, not built yet)")
-        fr = flow_videos.reshape(B * T, C, H, W)
+        fr = flow_videos.reshape(B * T, C, H, W)      # any H x W: Resize(R, BICUBIC) + CenterCrop(R) run PIL-exact on the GPU
         if fr.dtype != torch.uint8:
             # the reference casts to float and to_pil_image multiplies by 255 and wraps to u8 (:74,:78);
             # integer-valued floats in 0..255 are the same pixels as their u8 cast
