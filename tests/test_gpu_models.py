@@ -210,7 +210,9 @@ def test_adamw_matches_torch():
     assert abs(arena.grad_norm().item() - torch.cat([r.grad.reshape(-1) for r in ref]).norm().item()) < 1e-3
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,dh,masked", [(3, 8, 16, 15, 96, True), (2, 8, 16, 16, 64, False), (2, 2, 50, 50, 64, False)])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,masked", [(3, 8, 16, 15, 96, True), (2, 8, 16, 16, 64, False), (2, 2, 50, 50, 64, False),
+                                                  (2, 3, 197, 197, 64, False), (1, 2, 257, 257, 64, False), (2, 8, 40, 39, 96, True),
+                                                  (1, 1, 300, 300, 64, False)])     # last: does not fit LDS -> generic fp32 kernels
 def test_attention_backward_vs_torch(B, H, Tq, Tk, dh, masked):
     from vimo_clip_amd import autograd_ops as ag
     D = H * dh

@@ -488,6 +488,229 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __rest
   }
 }
 
+// ==================================================================================================
+// MFMA attention backward (no dropout): one workgroup of 4 waves per (batch, head); Q, K, V, dO of the head in LDS.
+//   phase A (a wave owns key tiles): P, dS in the S orientation (S = Q K^T: lane = key, registers = queries) are
+//            directly the B operands of dV^T += dO^T P and dK^T += Q^T dS (contraction over queries; dO^T / Q^T
+//            fragments by ds_read_b64_tr_b16);
+//   phase B (a wave owns query tiles): dS^T in the S^T orientation feeds dQ^T += K^T dS^T (contraction over keys).
+// Scores are recomputed from Q, K and the forward's log-sum-exp (two cheap MFMAs per tile pair); delta = rowsum(dO*O)
+// is computed in the prologue.  Rows of the LDS images are padded by 16 B when they fit, else unpadded.
+// ==================================================================================================
+template <typename T, int DH>
+__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                            const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
+                                                            const uint16_t* __restrict__ op, const uint16_t* __restrict__ dop,
+                                                            const float* __restrict__ lse, uint16_t* __restrict__ dqp,
+                                                            uint16_t* __restrict__ dkp, uint16_t* __restrict__ dvp, int H, int Tq,
+                                                            int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
+                                                            float scale, int RS) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = DH / 8, KK = DH / 32, DT = DH / 16;
+  const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;       // padded to whole 32-row steps (zero rows)
+  char* const q_lds = smem;
+  char* const do_lds = q_lds + TQP * RS;
+  char* const k_lds = do_lds + TQP * RS;
+  char* const v_lds = k_lds + TKP * RS;
+  float* const lse_s = (float*)(v_lds + TKP * RS);                // [TQP] log2-domain lse: lse * log2(e)
+  float* const del_s = lse_s + TQP;                               // [TQP] delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t qrow0 = (size_t)b * Tq, krow0 = (size_t)b * Tk;
+
+  // ---- stage Q, dO, K, V (zero padding rows); delta and lse ----
+  for (int idx = tid; idx < TQP * CH; idx += 256) {
+    const int row = idx / CH, c = idx % CH;
+    uint4 a = make_uint4(0, 0, 0, 0), d = a;
+    if (row < Tq) {
+      a = *(const uint4*)(qp + (qrow0 + row) * ldq + h * DH + c * 8);
+      d = *(const uint4*)(dop + (qrow0 + row) * ldo + h * DH + c * 8);
+    }
+    *(uint4*)(q_lds + row * RS + c * 16) = a;
+    *(uint4*)(do_lds + row * RS + c * 16) = d;
+  }
+  for (int idx = tid; idx < TKP * CH; idx += 256) {
+    const int row = idx / CH, c = idx % CH;
+    uint4 a = make_uint4(0, 0, 0, 0), d = a;
+    if (row < Tk) {
+      a = *(const uint4*)(kp + (krow0 + row) * ldk + h * DH + c * 8);
+      d = *(const uint4*)(vp + (krow0 + row) * ldv + h * DH + c * 8);
+    }
+    *(uint4*)(k_lds + row * RS + c * 16) = a;
+    *(uint4*)(v_lds + row * RS + c * 16) = d;
+  }
+  for (int row = tid; row < TQP; row += 256) {
+    float dl = 0.f, l2 = 0.f;
+    if (row < Tq) {
+      const uint16_t* o = op + (qrow0 + row) * ldo + h * DH;
+      const uint16_t* d = dop + (qrow0 + row) * ldo + h * DH;
+      for (int c = 0; c < DH; c += 8) {
+        const uint4 ow = *(const uint4*)(o + c), dw = *(const uint4*)(d + c);
+        const uint32_t oa[4] = {ow.x, ow.y, ow.z, ow.w}, da[4] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float o0, o1, d0, d1;
+          unpack2<T>(oa[j], o0, o1);
+          unpack2<T>(da[j], d0, d1);
+          dl += o0 * d0 + o1 * d1;
+        }
+      }
+      l2 = lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f;
+    }
+    del_s[row] = dl;
+    lse_s[row] = l2;
+  }
+  __syncthreads();
+
+  const float c2 = scale * 1.4426950408889634f;
+  const int nkt = TKP >> 4, nqt = TQP >> 4;
+
+  // ================= phase A: dK, dV =================
+  for (int nt = wave; nt < nkt; nt += 4) {
+    const int key = 16 * nt + r;                               // this lane's key column
+    const bool klive = key < Tk && (mask == nullptr || mask[(size_t)b * Tk + key] != 0);
+    uint4 kf[KK], vf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      kf[kk] = *(const uint4*)(k_lds + key * RS + (4 * kk + g) * 16);
+      vf[kk] = *(const uint4*)(v_lds + key * RS + (4 * kk + g) * 16);
+    }
+    f32x4 dvt[DT], dkt[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dvt[dt] = dkt[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < nqt / 2; ++s2) {
+      uint32_t pp[4], dd[4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * s2 + half;
+        f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = sc;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          const uint4 qf = *(const uint4*)(q_lds + (16 * qt + r) * RS + (4 * kk + g) * 16);
+          const uint4 df = *(const uint4*)(do_lds + (16 * qt + r) * RS + (4 * kk + g) * 16);
+          sc = T::mfma16(qf, kf[kk], sc);                      // S[query 4g+j][key r]
+          dp = T::mfma16(df, vf[kk], dp);                      // dP[query][key]
+        }
+        float pv[4], dv4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int qi = 16 * qt + 4 * g + j;
+          const float p = (klive && qi < Tq) ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], c2, -lse_s[qi])) : 0.f;
+          pv[j] = p;
+          dv4[j] = p * (dp[j] - del_s[qi]);
+        }
+        pp[2 * half] = pack2<T>(pv[0], pv[1]); pp[2 * half + 1] = pack2<T>(pv[2], pv[3]);
+        dd[2 * half] = pack2<T>(dv4[0], dv4[1]); dd[2 * half + 1] = pack2<T>(dv4[2], dv4[3]);
+      }
+      const uint4 pfrag = make_uint4(pp[0], pp[1], pp[2], pp[3]), dsfrag = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        // transposed 4-query x 16-column blocks of dO and Q: rows 32 s2 + 4 g + (r>>2) (+16), columns 16 dt + 4 (r&3)..
+        const int off = (32 * s2 + 4 * g + (r >> 2)) * RS + (16 * dt + 4 * (r & 3)) * 2;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(do_lds + off));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(do_lds + off + 16 * RS));
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(q_lds + off));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(q_lds + off + 16 * RS));
+        const uint2 x0 = __builtin_bit_cast(uint2, a0), x1 = __builtin_bit_cast(uint2, a1);
+        const uint2 y0 = __builtin_bit_cast(uint2, b0), y1 = __builtin_bit_cast(uint2, b1);
+        dvt[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pfrag, dvt[dt]);      // dV^T[d][key]
+        dkt[dt] = T::mfma16(make_uint4(y0.x, y0.y, y1.x, y1.y), dsfrag, dkt[dt]);     // dK^T[d][key]
+      }
+    }
+    if (key < Tk) {
+      uint16_t* dvr = dvp + (krow0 + key) * lddv + h * DH + 4 * g;
+      uint16_t* dkr = dkp + (krow0 + key) * lddk + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        *(uint2*)(dvr + 16 * dt) = make_uint2(pack2<T>(dvt[dt][0], dvt[dt][1]), pack2<T>(dvt[dt][2], dvt[dt][3]));
+        *(uint2*)(dkr + 16 * dt) = make_uint2(pack2<T>(dkt[dt][0] * scale, dkt[dt][1] * scale), pack2<T>(dkt[dt][2] * scale, dkt[dt][3] * scale));
+      }
+    }
+  }
+
+  // ================= phase B: dQ =================
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qi = 16 * qt + r;                                // this lane's query column
+    const bool qlive = qi < Tq;
+    const float l2 = lse_s[qi], dl = del_s[qi];
+    uint4 qf[KK], df[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      qf[kk] = *(const uint4*)(q_lds + qi * RS + (4 * kk + g) * 16);
+      df[kk] = *(const uint4*)(do_lds + qi * RS + (4 * kk + g) * 16);
+    }
+    f32x4 dqt[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dqt[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < nkt / 2; ++s2) {
+      uint32_t dd[4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int nt = 2 * s2 + half;
+        f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = sc;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          const uint4 kf = *(const uint4*)(k_lds + (16 * nt + r) * RS + (4 * kk + g) * 16);
+          const uint4 vf = *(const uint4*)(v_lds + (16 * nt + r) * RS + (4 * kk + g) * 16);
+          sc = T::mfma16(kf, qf[kk], sc);                      // S^T[key 4g+j][query r]
+          dp = T::mfma16(vf, df[kk], dp);
+        }
+        float dv4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = 16 * nt + 4 * g + j;
+          const bool live = qlive && key < Tk && (mask == nullptr || mask[(size_t)b * Tk + key] != 0);
+          const float p = live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], c2, -l2)) : 0.f;
+          dv4[j] = p * (dp[j] - dl);
+        }
+        dd[2 * half] = pack2<T>(dv4[0], dv4[1]); dd[2 * half + 1] = pack2<T>(dv4[2], dv4[3]);
+      }
+      const uint4 dsfrag = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (32 * s2 + 4 * g + (r >> 2)) * RS + (16 * dt + 4 * (r & 3)) * 2;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(k_lds + off));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)(k_lds + off + 16 * RS));
+        const uint2 x0 = __builtin_bit_cast(uint2, a0), x1 = __builtin_bit_cast(uint2, a1);
+        dqt[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), dsfrag, dqt[dt]);    // dQ^T[d][query]
+      }
+    }
+    if (qlive) {
+      uint16_t* dqr = dqp + (qrow0 + qi) * lddq + h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *(uint2*)(dqr + 16 * dt) = make_uint2(pack2<T>(dqt[dt][0] * scale, dqt[dt][1] * scale), pack2<T>(dqt[dt][2] * scale, dqt[dt][3] * scale));
+    }
+  }
+}
+
+template <typename T, int DH>
+static int launch_bwd_mfma(const void* q, const void* k, const void* v, const uint8_t* mask, const void* out, const void* dout,
+                           const float* lse, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv,
+                           int ldo, int lddq, int lddk, int lddv, float scale, hipStream_t s) {
+  const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;
+  int RS = DH * 2 + 16;
+  size_t lds = (size_t)2 * (TQP + TKP) * RS + (size_t)2 * TQP * sizeof(float);
+  if (lds > 160 * 1024) {
+    RS = DH * 2;
+    lds = (size_t)2 * (TQP + TKP) * RS + (size_t)2 * TQP * sizeof(float);
+  }
+  if (lds > 160 * 1024) return VMC_E_SHAPE;
+  auto kern = attn_bwd_mfma_kernel<T, DH>;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr = 160 * 1024;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, mask,
+                     (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, H, Tq, Tk, ldq, ldk,
+                     ldv, ldo, lddq, lddk, lddv, scale, RS);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 static int check_generic(int B, int H, int Tq, int Tk, int dh, int ldq, int ldk, int ldv, int ldo) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return VMC_E_ARG;
   if (dh <= 0 || dh > ATT_MAX_DH || (dh % 8) || Tk > ATT_MAX_TK || Tq > ATT_MAX_TK) return VMC_E_SHAPE;
@@ -536,6 +759,19 @@ extern "C" int vmc_attention_bwd(const void* q, const void* k, const void* v, co
   if (workspace_bytes < vmc_attention_bwd_workspace_bytes(B, H, Tq)) return VMC_E_ARG;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) return VMC_E_ALIGN;
   const float scale = 1.0f / sqrtf((float)dh);
+  if (dropout_p == 0.f && (dh == 64 || dh == 96) && ((lddq | lddk | lddv | ldo) % 4) == 0) {   // MFMA path when the head fits in LDS
+    const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;
+    if ((size_t)2 * (TQP + TKP) * dh * 2 + (size_t)2 * TQP * sizeof(float) <= 160 * 1024) {
+      hipStream_t st = (hipStream_t)stream;
+      if (dtype16 == VMC_BF16)
+        return dh == 64 ? launch_bwd_mfma<BF16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st)
+                        : launch_bwd_mfma<BF16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st);
+      if (dtype16 == VMC_F16)
+        return dh == 64 ? launch_bwd_mfma<F16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st)
+                        : launch_bwd_mfma<F16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st);
+      return VMC_E_DTYPE;
+    }
+  }
   float* delta = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
 #define VMC_LAUNCH_BWD(TT)                                                                                                   \
