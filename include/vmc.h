@@ -88,6 +88,14 @@ int vmc_linear(const void* A, const void* W, const float* bias, const void* res,
                int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                int dtype16, void* stream);
 
+/* Weight-gradient form of vmc_linear (autograd of F.linear w.r.t. the weight, train.py:104): C [M,N] f32 contiguous =
+ * A [M,K] @ W [N,K]^T with a long contraction K (the token count) and a small output.  128x128 tiles x K slices; every
+ * slice writes a partial slab into the workspace, a second kernel sums the slabs in a fixed order (deterministic).
+ * K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0; workspace >= vmc_linear_splitk_workspace_bytes (may be 0 -> NULL). */
+size_t vmc_linear_splitk_workspace_bytes(int M, int N, int K);
+int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, void* workspace,
+                          size_t workspace_bytes, int dtype16, void* stream);
+
 /* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
  * 1 = 8-phase 256x256 kernel, one tile per workgroup (default), 2 = persistent 8-phase kernel.  Results are
  * identical bit for bit across the three. */
@@ -102,7 +110,7 @@ int vmc_transpose16(const void* in, void* out, int rows, int cols, int ld_in, in
 int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows, int cols, int ld_out, int ld_out_t,
                     int dtype16, void* stream);
 
-/* Column sums  out[n] = sum_m in[m, n]  (bias gradients, K8).  workspace: >= vmc_colsum_workspace_bytes. */
+/* Column sums  out[n] = sum_m in[m, n]  (bias gradients, K8).  N % 4 == 0, ld_in % 4 == 0.  workspace: >= vmc_colsum_workspace_bytes. */
 size_t vmc_colsum_workspace_bytes(int M, int N);
 int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype, void* workspace,
                size_t workspace_bytes, void* stream);

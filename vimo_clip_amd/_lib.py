@@ -27,6 +27,8 @@ SIGNATURES = {
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
     "vmc_resample_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
+    "vmc_linear_splitk_workspace_bytes": (Z, [I, I, I]),
+    "vmc_linear_splitk_f32": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
     "vmc_set_gemm_variant": (I, [I]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),

@@ -159,14 +159,14 @@ class LinearFn(torch.autograd.Function):
             if Kx == K and K % 4 == 0:
                 slot = getattr(weight, "_vmc_grad", None)
                 if rows is not None and slot is not None:
-                    ops.linear(dzt, xt, out=slot.view(weight.shape[0], K)[lo:hi])      # in place into the parameter's rows
+                    ops.linear_wgrad(dzt, xt, slot.view(weight.shape[0], K)[lo:hi])      # in place into the parameter's rows
                     dw = slot
                 elif rows is not None:
                     dw = torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
-                    ops.linear(dzt, xt, out=dw[lo:hi])
+                    ops.linear_wgrad(dzt, xt, dw[lo:hi])
                 else:
                     out = _grad_out(weight, (N, K))
-                    ops.linear(dzt, xt, out=out.view(N, K))
+                    ops.linear_wgrad(dzt, xt, out.view(N, K))
                     dw = out
             else:
                 full = ops.linear(dzt, xt, out_dtype=torch.float32)                    # [N, Kx]

@@ -90,7 +90,7 @@ class _ProjFn(torch.autograd.Function):
         dyt = torch.zeros((E, Mp), dtype=dt16, device=x16.device)
         ag.check(ag.lib.vmc_transpose16(ag.ptr(dy16), ag.ptr(dyt), M, E, dy16.stride(0), Mp, ag.stream()), "transpose16")
         out = ag._grad_out(proj, (D, E))
-        ops.linear(xt, dyt, out=out)                                              # dproj[D,E] = x^T dy
+        ops.linear_wgrad(xt, dyt, out)                                            # dproj[D,E] = x^T dy
         return dx, ag._deliver(proj, out)
 
 

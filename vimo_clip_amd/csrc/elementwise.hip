@@ -238,19 +238,43 @@ extern "C" int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows,
 
 // ---- column sums (bias gradients): partials per row-slab, then a reduce ---------------------------
 #define COLSUM_SLABS 256
+// partial[slab, n] = sum of rows [slab*rp, (slab+1)*rp): 64 lanes x 4 columns (8-/16-byte loads) across, 4 row
+// phases per block combined through LDS
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const void* __restrict__ in, float* __restrict__ partial, int M, int N,
                                                              size_t ld, int in_f32) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  __shared__ float4 sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + tx) * 4;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-  float a = 0.f;
-  if (in_f32)
-    for (int r = r0; r < r1; ++r) a += ((const float*)in)[(size_t)r * ld + col];
-  else
-    for (int r = r0; r < r1; ++r) a += T::to_f32(((const uint16_t*)in)[(size_t)r * ld + col]);
-  partial[(size_t)blockIdx.y * N + col] = a;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < N) {
+    if (in_f32) {
+      for (int r = r0 + ty; r < r1; r += 4) {
+        const float4 v = *(const float4*)((const float*)in + (size_t)r * ld + col);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    } else {
+      for (int r = r0 + ty; r < r1; r += 4) {
+        const uint2 w = *(const uint2*)((const uint16_t*)in + (size_t)r * ld + col);
+        float x0, x1, x2, x3;
+        unpack2<T>(w.x, x0, x1);
+        unpack2<T>(w.y, x2, x3);
+        a.x += x0; a.y += x1; a.z += x2; a.w += x3;
+      }
+    }
+  }
+  sm[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    float4 o;
+    o.x = (sm[0][tx].x + sm[1][tx].x) + (sm[2][tx].x + sm[3][tx].x);
+    o.y = (sm[0][tx].y + sm[1][tx].y) + (sm[2][tx].y + sm[3][tx].y);
+    o.z = (sm[0][tx].z + sm[1][tx].z) + (sm[2][tx].z + sm[3][tx].z);
+    o.w = (sm[0][tx].w + sm[1][tx].w) + (sm[2][tx].w + sm[3][tx].w);
+    *(float4*)(partial + (size_t)blockIdx.y * N + col) = o;
+  }
 }
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, int W) {
   __shared__ float sm[4][64];
@@ -278,8 +302,9 @@ extern "C" int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, i
                           void* stream) {
   if (!in || !out || !workspace || M <= 0 || N <= 0 || ld_in < N) return VMC_E_ARG;
   if (workspace_bytes < vmc_colsum_workspace_bytes(M, N)) return VMC_E_ARG;
+  if ((N % 4) || (ld_in % 4)) return VMC_E_ALIGN;
   const int slabs = colsum_slabs(M);
-  dim3 grid((N + 255) / 256, slabs);
+  dim3 grid((N / 4 + 63) / 64, slabs);
   hipStream_t s = (hipStream_t)stream;
   if (in_dtype == VMC_F16)
     hipLaunchKernelGGL(colsum_partial_kernel<F16>, grid, dim3(256), 0, s, in, (float*)workspace, M, N, (size_t)ld_in, 0);

@@ -106,7 +106,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
     for (int nt = 0; nt < 4; ++nt) woff[kk][nt] = Cfg::A_BYTES + lds_off_w(wn * 64 + gemm_w_row(r, nt), 4 * kk + q);
   }
 
-  const int nkt = g.K / 64;
+  // split-K: blockIdx.y owns K tiles [kt0, kt0 + nkt) (k_slices == 1: the whole K range)
+  const int nkt_all = g.K / 64;
+  const int per_slice = (nkt_all + g.k_slices - 1) / g.k_slices;
+  const int kt0 = blockIdx.y * per_slice;
+  const int nkt = min(nkt_all, kt0 + per_slice) - kt0;
+  if (nkt <= 0) return;
+#pragma unroll
+  for (int i = 0; i < Cfg::A_ITERS; ++i) a_src[i] += (size_t)kt0 * 128;
+#pragma unroll
+  for (int i = 0; i < Cfg::B_ITERS; ++i) b_src[i] += (size_t)kt0 * 128;
   char* const buf0 = smem;
   char* const buf1 = smem + Cfg::STAGE;
   // prologue: tile 0 -> buf0
@@ -134,6 +143,18 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
 
   // ---- epilogue: lane owns C[row][col0 .. col0+15] for each mt ----
   const int col0 = n0 + wn * 64 + 16 * q;
+  if (g.k_slices > 1) {   // split-K: slice s writes its partial tile into slab s of the workspace (plain 16-byte stores)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = m0 + wm * 16 * MT + 16 * mt + r;
+      if (row >= g.M) continue;
+      float* dst = (float*)g.C + ((size_t)blockIdx.y * g.M + row) * g.ldc + col0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        if (col0 + 4 * nt < g.N) *(float4*)(dst + 4 * nt) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+    }
+    return;
+  }
   const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.res == nullptr || (g.ldres & 7) == 0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -204,7 +225,7 @@ static int launch_cfg(GemmArgs& g, hipStream_t stream) {
   }
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
   g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(Cfg::NT), Cfg::LDS, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.k_slices), dim3(Cfg::NT), Cfg::LDS, stream, g);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -260,10 +281,64 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   g.alpha = alpha; g.out_f32 = (out_dtype == VMC_F32); g.res_f32 = (res_dtype == VMC_F32);
   g.out_row_group = out_row_group; g.res_row_mod = res_row_mod;
   g.tiles_m = g.tiles_n = 0;
+  g.k_slices = 1;
   // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
   // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
   if (dtype16 == VMC_BF16) return launch_act<BF16>(g, act, (hipStream_t)stream);
   return launch_act<F16>(g, act, (hipStream_t)stream);
+}
+
+
+// out[w] = sum_p partial[p*W + w], float4 per thread, fixed order (deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int P, size_t W4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < W4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = ((const float4*)partial)[i];
+    for (int p = 1; p < P; ++p) {
+      const float4 v = ((const float4*)partial)[(size_t)p * W4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    ((float4*)out)[i] = a;
+  }
+}
+
+static int splitk_slices(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int slices = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU
+  const int nkt = K / 64;
+  if (slices > nkt / 4) slices = nkt / 4;              // at least 4 K tiles per slice
+  return slices < 1 ? 1 : slices;
+}
+
+// Weight-gradient GEMM (K8): C[M,N] (f32, contiguous) = A[M,K] @ W[N,K]^T with a long contraction (K = tokens) and a
+// small output: 128x128 tiles x K slices so that the grid covers the chip; every slice writes a partial slab into the
+// workspace and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
+extern "C" size_t vmc_linear_splitk_workspace_bytes(int M, int N, int K) {
+  const int s = splitk_slices(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, void* workspace,
+                                     size_t workspace_bytes, int dtype16, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
+  if (K % 64 != 0 || N % 4 != 0) return VMC_E_SHAPE;
+  if (lda % 8 || ldw % 8) return VMC_E_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)workspace) & 15) return VMC_E_ALIGN;
+  const int slices = splitk_slices(M, N, K);
+  if (slices > 1 && (!workspace || workspace_bytes < vmc_linear_splitk_workspace_bytes(M, N, K))) return VMC_E_ARG;
+  GemmArgs g;
+  g.A = (const char*)A; g.W = (const char*)W; g.bias = nullptr; g.res = nullptr;
+  g.C = slices > 1 ? (char*)workspace : (char*)C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = N; g.ldres = 0;
+  g.alpha = 1.0f; g.out_f32 = 1; g.res_f32 = 0; g.out_row_group = 0; g.res_row_mod = 0;
+  g.k_slices = slices;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = dtype16 == VMC_BF16 ? launch_cfg<BF16, VMC_ACT_NONE, 4, 2, 2>(g, s)
+           : dtype16 == VMC_F16 ? launch_cfg<F16, VMC_ACT_NONE, 4, 2, 2>(g, s) : VMC_E_DTYPE;
+  if (rc || slices == 1) return rc;
+  const size_t W4 = (size_t)M * N / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(W4, 256)), dim3(256), 0, s, (const float*)workspace, C, slices, W4);
+  VMC_CHECK_LAUNCH();
+  return 0;
 }

@@ -14,6 +14,7 @@ struct GemmArgs {
   int out_f32, res_f32;
   int out_row_group, res_row_mod;
   int tiles_m, tiles_n;
+  int k_slices;   // > 1: split-K (gemm_kernel only): blockIdx.y owns a K range and atomically adds into the f32 output
 };
 
 // One lane's run of NV (8 or 16) consecutive output columns of one row.

@@ -73,6 +73,21 @@ def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = A
     return out
 
 
+def linear_wgrad(a: torch.Tensor, w16: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[M,N] (f32, contiguous, overwritten) = a[M,K] @ w16[N,K]^T for weight gradients: split-K when the output is
+    small and the contraction long (vmc_linear_splitk_f32), the plain tiled GEMM otherwise."""
+    M, K = a.shape
+    N = w16.shape[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if out.is_contiguous() and tiles < 384 and K >= 1024:
+        nbytes = lib.vmc_linear_splitk_workspace_bytes(M, N, K)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device) if nbytes else None
+        check(lib.vmc_linear_splitk_f32(ptr(a), ptr(w16), ptr(out), M, N, K, a.stride(0), w16.stride(0), ptr(ws), nbytes, dt(a), stream()),
+              "linear_splitk_f32")
+        return out
+    return linear(a, w16, out=out)
+
+
 def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False, y32=None, rows=None, ldx=None,
               eps: float = 1e-5, save_stats: bool = False):
     """LayerNorm over the last dim of x viewed as [rows, D] with row stride ldx.  Returns (y16, y32, mean, rstd)."""
