@@ -96,6 +96,14 @@ size_t vmc_linear_splitk_workspace_bytes(int M, int N, int K);
 int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int M, int N, int K, int lda, int ldw, void* workspace,
                           size_t workspace_bytes, int dtype16, void* stream);
 
+/* Weight gradient straight from the token-major operands the forward left behind (no transposed copies):
+ * C [N,K] f32 contiguous = dY[M,N]^T @ X[M,K], contraction over the M tokens (any M; rows past M read as zeros).
+ * Both MFMA operands come from [64 tokens][128 columns] LDS tiles through ds_read_b64_tr_b16.  Token range split in
+ * slices -> slabs in the workspace + deterministic reduce.  N % 8 == 0, K % 8 == 0, lddy/ldx % 8 == 0. */
+size_t vmc_linear_wgrad_tn_workspace_bytes(int M, int N, int K);
+int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, void* workspace,
+                        size_t workspace_bytes, int dtype16, void* stream);
+
 /* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
  * 1 = 8-phase 256x256 kernel, one tile per workgroup (default), 2 = persistent 8-phase kernel.  Results are
  * identical bit for bit across the three. */

@@ -217,3 +217,30 @@ def test_transpose_colsum_cast_pool_pe(ops):
         v = torch.randn(1000, generator=g).to(torch.float16)
         ref = {1: v.float() * torch.sigmoid(1.702 * v.float()), 2: torch.nn.functional.gelu(v.float()), 3: torch.relu(v.float())}[act]
         torch.testing.assert_close(ops.act_fwd(v.to(DEV), act).float().cpu(), ref, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 768, 2048), (130, 64, 40), (4096, 512, 2048), (65536, 512, 512)])
+def test_wgrad_tn_exact_integers(ops, dtype, M, N, K):
+    # dW = dY^T X straight from token-major operands (ds_read_b64_tr_b16 fragments, split over the token range)
+    dy = _ints((M, N), -2, 2, 31)
+    x = _ints((M, K), -3, 3, 32)
+    dy[:, 1] += (torch.arange(M) % 3).float()
+    x[:, 2] += (torch.arange(M) % 2).float()
+    ref = dy.t() @ x
+    assert ref.abs().max() < 2 ** 24
+    out = ops.wgrad_tn(dy.to(DEV, dtype), x.to(DEV, dtype), torch.empty(N, K, device=DEV))
+    assert torch.equal(out.cpu(), ref), f"max diff {(out.cpu() - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 2048, 4096), (512, 512, 65536), (768, 768, 25600), (64, 144, 1088), (768, 3072, 1024)])
+def test_linear_wgrad_splitk_exact_integers(ops, M, N, K):
+    # NT split-K path (vmc_linear_splitk_f32): every slab written (no empty trailing slice), deterministic reduce
+    a = _ints((M, K), -2, 2, 41)
+    w = _ints((N, K), -3, 3, 42)
+    ref = a @ w.t()
+    assert ref.abs().max() < 2 ** 24
+    out = ops.linear_wgrad(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), torch.empty(M, N, device=DEV))
+    assert torch.equal(out.cpu(), ref), f"max diff {(out.cpu() - ref).abs().max()}"
+    again = ops.linear_wgrad(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), torch.full((M, N), 7.0, device=DEV))
+    assert torch.equal(again, out)

@@ -29,6 +29,8 @@ SIGNATURES = {
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
     "vmc_linear_splitk_workspace_bytes": (Z, [I, I, I]),
     "vmc_linear_splitk_f32": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
+    "vmc_linear_wgrad_tn_workspace_bytes": (Z, [I, I, I]),
+    "vmc_linear_wgrad_tn": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
     "vmc_set_gemm_variant": (I, [I]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),

@@ -150,27 +150,37 @@ class LinearFn(torch.autograd.Function):
         # ---- wgrad: dW = dz^T @ x  (contraction over M; transposed operands, M zero-padded to 64) ----
         dw = None
         if weight.requires_grad:
-            Mp = _pad64(M)
-            dzt = torch.zeros((N, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((N, Mp), dtype=dt16, device=dz.device)
-            check(lib.vmc_transpose16(ptr(dz), ptr(dzt), M, N, dz.stride(0), Mp, stream()), "transpose16")
             Kx = x.shape[1]
-            xt = torch.zeros((Kx, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((Kx, Mp), dtype=dt16, device=dz.device)
-            check(lib.vmc_transpose16(ptr(x), ptr(xt), M, Kx, x.stride(0), Mp, stream()), "transpose16")
-            if Kx == K and K % 4 == 0:
-                slot = getattr(weight, "_vmc_grad", None)
-                if rows is not None and slot is not None:
-                    ops.linear_wgrad(dzt, xt, slot.view(weight.shape[0], K)[lo:hi])      # in place into the parameter's rows
-                    dw = slot
-                elif rows is not None:
-                    dw = torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
-                    ops.linear_wgrad(dzt, xt, dw[lo:hi])
-                else:
-                    out = _grad_out(weight, (N, K))
-                    ops.linear_wgrad(dzt, xt, out.view(N, K))
-                    dw = out
+            slot = getattr(weight, "_vmc_grad", None)
+            if N % 8 == 0 and Kx % 8 == 0:
+                # TN kernel on the token-major operands as they are (contraction over the M tokens)
+                if Kx == K:
+                    if rows is not None:
+                        if slot is not None:
+                            ops.wgrad_tn(dz, x, slot.view(weight.shape[0], K)[lo:hi])
+                            dw = slot
+                        else:
+                            dw = torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
+                            ops.wgrad_tn(dz, x, dw[lo:hi])
+                    else:
+                        dw = ops.wgrad_tn(dz, x, _grad_out(weight, (N, K)).view(N, K))
+                else:                                                                   # K-padded x (patch GEMM)
+                    full = ops.wgrad_tn(dz, x, torch.empty((N, Kx), dtype=torch.float32, device=dz.device))
+                    dw = full[:, :K].contiguous()
             else:
-                full = ops.linear(dzt, xt, out_dtype=torch.float32)                    # [N, Kx]
-                dw = full[:, :K].contiguous()
+                # odd widths: transposed operands (M zero-padded to 64) through the NT kernel
+                Mp = _pad64(M)
+                dzt = torch.zeros((N, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((N, Mp), dtype=dt16, device=dz.device)
+                check(lib.vmc_transpose16(ptr(dz), ptr(dzt), M, N, dz.stride(0), Mp, stream()), "transpose16")
+                xt = torch.zeros((Kx, Mp), dtype=dt16, device=dz.device) if Mp != M else torch.empty((Kx, Mp), dtype=dt16, device=dz.device)
+                check(lib.vmc_transpose16(ptr(x), ptr(xt), M, Kx, x.stride(0), Mp, stream()), "transpose16")
+                full = ops.linear_wgrad(dzt, xt, torch.empty((N, Kx), dtype=torch.float32, device=dz.device))
+                dwp = full[:, :K] if Kx != K else full
+                if rows is not None:
+                    dw = slot if slot is not None else torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
+                    dw.view(weight.shape[0], K)[lo:hi].copy_(dwp)
+                else:
+                    dw = dwp.contiguous()
         db = None
         if bias is not None and bias.requires_grad:
             db = ops.colsum(dz)

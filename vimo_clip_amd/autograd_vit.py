@@ -84,13 +84,16 @@ class _ProjFn(torch.autograd.Function):
             dyp = torch.zeros((M, w.shape[1]), dtype=dt16, device=dy16.device)
             dyp[:, :E].copy_(dy16)
         dx = ops.linear(dyp, w)                                                    # [M,E] @ [D,E]^T -> [M,D]
-        Mp = ag._pad64(M)
-        xt = torch.zeros((D, Mp), dtype=dt16, device=x16.device)
-        ag.check(ag.lib.vmc_transpose16(ag.ptr(x16), ag.ptr(xt), M, D, x16.stride(0), Mp, ag.stream()), "transpose16")
-        dyt = torch.zeros((E, Mp), dtype=dt16, device=x16.device)
-        ag.check(ag.lib.vmc_transpose16(ag.ptr(dy16), ag.ptr(dyt), M, E, dy16.stride(0), Mp, ag.stream()), "transpose16")
         out = ag._grad_out(proj, (D, E))
-        ops.linear_wgrad(xt, dyt, out)                                            # dproj[D,E] = x^T dy
+        if D % 8 == 0 and E % 8 == 0:
+            ops.wgrad_tn(x16, dy16, out)                                            # dproj[D,E] = x^T dy
+        else:
+            Mp = ag._pad64(M)
+            xt = torch.zeros((D, Mp), dtype=dt16, device=x16.device)
+            ag.check(ag.lib.vmc_transpose16(ag.ptr(x16), ag.ptr(xt), M, D, x16.stride(0), Mp, ag.stream()), "transpose16")
+            dyt = torch.zeros((E, Mp), dtype=dt16, device=x16.device)
+            ag.check(ag.lib.vmc_transpose16(ag.ptr(dy16), ag.ptr(dyt), M, E, dy16.stride(0), Mp, ag.stream()), "transpose16")
+            ops.linear_wgrad(xt, dyt, out)
         return dx, ag._deliver(proj, out)
 
 

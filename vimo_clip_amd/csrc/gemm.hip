@@ -308,7 +308,9 @@ static int splitk_slices(int M, int N, int K) {
   int slices = (768 + tiles - 1) / tiles;              // ~3 workgroups per CU
   const int nkt = K / 64;
   if (slices > nkt / 4) slices = nkt / 4;              // at least 4 K tiles per slice
-  return slices < 1 ? 1 : slices;
+  if (slices < 1) slices = 1;
+  const int per = (nkt + slices - 1) / slices;         // the kernel's per-slice tile count ...
+  return (nkt + per - 1) / per;                        // ... and no empty trailing slice (its slab would stay unwritten)
 }
 
 // Weight-gradient GEMM (K8): C[M,N] (f32, contiguous) = A[M,K] @ W[N,K]^T with a long contraction (K = tokens) and a
@@ -342,3 +344,5 @@ extern "C" int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int
   VMC_CHECK_LAUNCH();
   return 0;
 }
+
+

@@ -1,0 +1,224 @@
+// TN weight-gradient GEMM:  C[N,K] (f32) = dY[M,N]^T @ X[M,K], both operands token-major exactly as the forward
+// pass left them -- no transposed copies.  The contraction runs over the M tokens.
+//
+// Block tile 256 (n) x 128 (k), 8 waves as 4 (n) x 2 (k), each wave 64 x 64 = 4 x 4 MFMA tiles.  64 tokens per
+// pipeline stage.  A stage holds three [64 tokens][128 columns] sub-tiles (256-B rows of sixteen 16-B chunks): dY
+// columns 0..127, dY columns 128..255, X columns 0..127.  They are filled by global_load_lds_dwordx4 (lane-linear
+// LDS image; the XOR swizzle of the chunk slot by the token row is applied on the SOURCE address) into a 3-stage ring
+// (144 KiB), two stages in flight ahead of the MFMAs, counted vmcnt.  Both MFMA operands are fetched with
+// ds_read_b64_tr_b16: lane (c = lane & 15, g = lane >> 4) receives tokens 8g..8g+7 of column c, the k-slots of
+// v_mfma_f32_16x16x32.  With the swizzle slot = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) the 32 lanes of one
+// transposed read touch 32 distinct 8-byte units of 64 banks (conflict free).
+// The token range is split in slices (blockIdx.y): slabs in a workspace + deterministic reduce, as the NT split-K.
+#include "gemm_common.h"
+
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ uint32_t tn_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(const VMC_LDS char*)p; }
+
+// inline asm for the reason given in gemm8.hip: hipcc would drain vmcnt(0) in front of C++ LDS reads while LDS-DMA
+// is in flight.  Completion is ordered by the explicit lgkmcnt wait in front of the MFMAs.
+template <int IMM>
+__device__ __forceinline__ void tn_read_tr(uint2& v, uint32_t addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+}
+
+constexpr int TN_SUB = 64 * 256;        // one sub-tile
+constexpr int TN_STAGE = 3 * TN_SUB;    // 48 KiB
+constexpr int TN_STAGES = 3;
+
+template <typename T>
+__global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ C,
+                                                      int M, int N, int K, int lddy, int ldx, int tiles_k, int slices) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int r = lane & 15, g = lane >> 4, q = r >> 2, p = r & 3;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * 256, k0 = tk * 128;
+  const int steps_all = (M + 63) / 64;
+  const int per = (steps_all + slices - 1) / slices;
+  const int s0 = blockIdx.y * per, s1 = min(steps_all, s0 + per);
+
+  // LDS-DMA sources: image chunk c = i*512 + tid of a sub-tile -> token row c>>4, slot c&15, source chunk slot^swz(row).
+  // Columns past the matrix edge are clamped to the tile's first column (in bounds; those outputs are never stored);
+  // token rows past M are clamped to M-1 and zeroed in LDS before use (tail stage only).
+  const uint16_t* src[6];
+  int srow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid, row = c >> 4, ch = (c & 15) ^ tn_swz(row);
+    srow[i] = row;
+    int col = n0 + ch * 8;
+    src[i] = dY + (col < N ? col : n0);
+    col = n0 + 128 + ch * 8;
+    src[2 + i] = dY + (col < N ? col : n0);
+    col = k0 + ch * 8;
+    src[4 + i] = X + (col < K ? col : k0);
+  }
+  const int wave_lds = wave * 1024;   // 64 lanes x 16 B
+  auto stage_in = [&](int step) {
+    char* dst = smem + (step % TN_STAGES) * TN_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(step * 64 + srow[i], M - 1);
+#pragma unroll
+      for (int sub = 0; sub < 3; ++sub) {
+        const size_t ld = sub < 2 ? (size_t)lddy : (size_t)ldx;
+        __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(src[2 * sub + i] + (size_t)m * ld),
+                                         (VMC_LDS void*)(dst + sub * TN_SUB + i * 8192 + wave_lds), 16, 0, 0);
+      }
+    }
+  };
+
+  // transposed-read offsets inside a stage: token row 8g + q (+4 for the second half), columns 16 t + 4 p of the wave's
+  // 64-column window; ks (32 tokens) adds 8192 bytes as an immediate.
+  uint32_t aoff[4][2], boff[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int row = 8 * g + q + 4 * e;
+      const int cha = ((wn & 1) * 64 + 16 * t + 4 * p) >> 3, chb = (wk * 64 + 16 * t + 4 * p) >> 3;
+      aoff[t][e] = (wn >> 1) * TN_SUB + row * 256 + ((cha ^ tn_swz(row)) << 4) + (p & 1) * 8;
+      boff[t][e] = 2 * TN_SUB + row * 256 + ((chb ^ tn_swz(row)) << 4) + (p & 1) * 8;
+    }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (s0 < s1) {
+    stage_in(s0);
+    if (s0 + 1 < s1) stage_in(s0 + 1);
+    for (int st = s0; st < s1; ++st) {
+      if (st + 1 < s1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // stage st landed for every wave; everyone is done reading stage st-1
+      __builtin_amdgcn_sched_barrier(0);     // (raw barrier: __syncthreads would drain the DMAs still in flight)
+      if (st + 2 < s1) stage_in(st + 2);     // into the ring slot of stage st-1
+      char* cur = smem + (st % TN_STAGES) * TN_STAGE;
+      if (st * 64 + 64 > M) {                // tail stage: token rows past M become zeros in all three sub-tiles
+        const int valid = M - st * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (srow[i] >= valid) {
+#pragma unroll
+            for (int sub = 0; sub < 3; ++sub) *(uint4*)(cur + sub * TN_SUB + (i * 512 + tid) * 16) = make_uint4(0, 0, 0, 0);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t base = tn_lds_addr(cur);
+      uint2 af[2][4][2], bf[2][4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          tn_read_tr<0>(af[0][t][e], base + aoff[t][e]);
+          tn_read_tr<0>(bf[0][t][e], base + boff[t][e]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)                 // second 32 tokens: in flight under the first 16 MFMAs
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          tn_read_tr<8192>(af[1][t][e], base + aoff[t][e]);
+          tn_read_tr<8192>(bf[1][t][e], base + boff[t][e]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = T::mfma16(make_uint4(af[0][a][0].x, af[0][a][0].y, af[0][a][1].x, af[0][a][1].y),
+                                make_uint4(bf[0][b][0].x, bf[0][b][0].y, bf[0][b][1].x, bf[0][b][1].y), acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = T::mfma16(make_uint4(af[1][a][0].x, af[1][a][0].y, af[1][a][1].x, af[1][a][1].y),
+                                make_uint4(bf[1][b][0].x, bf[1][b][0].y, bf[1][b][1].x, bf[1][b][1].y), acc[a][b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // lane holds C[n = n0 + 64 wn + 16 a + 4 g + j][k = k0 + 64 wk + 16 b + r]
+  float* out = C + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 64 * wn + 16 * a + 4 * g + j;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = k0 + 64 * wk + 16 * b + r;
+        if (k < K) out[(size_t)n * K + k] = acc[a][b][j];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int slices, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = ((const float4*)slabs)[i];
+  for (int k = 1; k < slices; ++k) {
+    const float4 v = ((const float4*)slabs)[(size_t)k * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  ((float4*)out)[i] = s;
+}
+
+static int tn_slices(int M, int N, int K) {
+  const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
+  int slices = (512 + tiles - 1) / tiles;
+  const int steps = (M + 63) / 64;
+  if (slices > steps / 4) slices = steps / 4;
+  if (slices < 1) slices = 1;
+  const int per = (steps + slices - 1) / slices;
+  return (steps + per - 1) / per;                      // no empty trailing slice
+}
+extern "C" size_t vmc_linear_wgrad_tn_workspace_bytes(int M, int N, int K) {
+  const int s = tn_slices(M, N, K);
+  return s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+}
+extern "C" int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, void* workspace,
+                                   size_t workspace_bytes, int dtype16, void* stream) {
+  if (!dY || !X || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
+  if ((N % 8) || (K % 8)) return VMC_E_SHAPE;
+  if ((lddy % 8) || (ldx % 8)) return VMC_E_ALIGN;
+  if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)C | (uintptr_t)workspace) & 15) return VMC_E_ALIGN;
+  const int slices = tn_slices(M, N, K);
+  if (slices > 1 && (!workspace || workspace_bytes < vmc_linear_wgrad_tn_workspace_bytes(M, N, K))) return VMC_E_ARG;
+  float* dst = slices > 1 ? (float*)workspace : C;
+  const int tiles_k = (K + 127) / 128;
+  dim3 grid(((N + 255) / 256) * tiles_k, slices);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)TN_STAGES * TN_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(gemm_tn_kernel<BF16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, M, N, K, lddy, ldx, tiles_k, slices);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(gemm_tn_kernel<F16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, M, N, K, lddy, ldx, tiles_k, slices);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  if (slices > 1) {
+    const size_t n4 = (size_t)N * K / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, slices, n4);
+    VMC_CHECK_LAUNCH();
+  }
+  return 0;
+}

@@ -88,6 +88,17 @@ def linear_wgrad(a: torch.Tensor, w16: torch.Tensor, out: torch.Tensor) -> torch
     return linear(a, w16, out=out)
 
 
+def wgrad_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[N,K] (f32, contiguous, overwritten) = dy[M,N]^T @ x[M,K] (vmc_linear_wgrad_tn): no transposed copies."""
+    M, N = dy.shape
+    K = x.shape[1]
+    nbytes = lib.vmc_linear_wgrad_tn_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
+    check(lib.vmc_linear_wgrad_tn(ptr(dy), ptr(x), ptr(out), M, N, K, dy.stride(0), x.stride(0), ptr(ws), nbytes, dt(dy), stream()),
+          "linear_wgrad_tn")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False, y32=None, rows=None, ldx=None,
               eps: float = 1e-5, save_stats: bool = False):
     """LayerNorm over the last dim of x viewed as [rows, D] with row stride ldx.  Returns (y16, y32, mean, rstd)."""
