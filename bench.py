@@ -105,10 +105,11 @@ def tfam_extras(dev, rank, world, cdt):
 
     t = _time_cuda(train_step, 10)
     if world > 1:
-        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        tt = torch.tensor([t], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
-    out["tfam_train_clips_per_s_B512_per_gpu"] = round(B * world / t, 1)
+    out["tfam_train_clips_per_s"] = round(B * world / t, 1)          # whole job, per-GPU batch 512 (weak scaling)
+    out["tfam_train_per_gpu_batch"] = B
     out["tfam_train_ms_per_step"] = round(1e3 * t, 3)
     out["tfam_grad_allreduce_bytes"] = arena.numel * 4
     # AdamW kernel alone: HIP events on the launch stream, HBM roofline (16 B read + 12 B write per parameter)
@@ -147,7 +148,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") in production; VMC_BENCH_BACKEND=gloo rehearses the N>1 control flow with several ranks
+        # sharing one GPU (the 1-GPU development boxes), where RCCL refuses duplicate devices.
+        backend = os.environ.get("VMC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(1, torch.cuda.device_count())
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -180,7 +188,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()

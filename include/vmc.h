@@ -105,8 +105,9 @@ int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, i
                         size_t workspace_bytes, int dtype16, void* stream);
 
 /* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
- * 1 = 8-phase 256x256 kernel, one tile per workgroup (default), 2 = persistent 8-phase kernel.  Results are
- * identical bit for bit across the three. */
+ * 1 = 8-phase 256x256 kernel, one tile per workgroup, with the tile rows of a small last partial round (T mod 256 tiles)
+ * handed to the small-tile kernel in a second launch (default), 2 = persistent 8-phase kernel, 3 = as 1 without the
+ * tail-row split.  Results are identical bit for bit across all of them. */
 int vmc_set_gemm_variant(int variant);
 
 /* 16-bit 2-D transpose  out[c, r] = in[r, c]  (rows x cols, element strides ld_in / ld_out); used for

@@ -254,11 +254,12 @@ static int launch_act(GemmArgs& g, int act, hipStream_t stream) {
 
 static int g_gemm_variant = []() {
   const char* e = getenv("VMC_GEMM8");
-  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
 }();
 int vmc_gemm_variant() { return g_gemm_variant; }
+
 extern "C" int vmc_set_gemm_variant(int v) {
-  if (v < 0 || v > 2) return VMC_E_ARG;
+  if (v < 0 || v > 3) return VMC_E_ARG;
   g_gemm_variant = v;
   return 0;
 }
@@ -285,7 +286,28 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
   // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
+  if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) {
+    // Round quantisation: T tiles on 256 CUs cost ceil(T/256) tile-times.  When the last, partial round holds only a few
+    // tiles that are whole tile rows (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4),
+    // those rows go to the small-tile kernel, which spreads them over the whole chip, in a second launch.
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+    const long tail = t256 % 256;
+    if (vmc_gemm_variant() == 1 && !out_row_group && !res_row_mod && t256 >= 512 && tail > 0 && tail <= 64 &&
+        tail % tn == 0) {
+      const int m_main = (tm - (int)(tail / tn)) * 256;
+      GemmArgs t = g;
+      g.M = m_main;
+      int rc = vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
+      if (rc) return rc;
+      t.M = M - m_main;
+      t.A += (size_t)m_main * lda * 2;
+      t.C += (size_t)m_main * ldc * (t.out_f32 ? 4 : 2);
+      if (t.res) t.res += (size_t)m_main * ldres * (t.res_f32 ? 4 : 2);
+      if (dtype16 == VMC_BF16) return launch_act<BF16>(t, act, (hipStream_t)stream);
+      return launch_act<F16>(t, act, (hipStream_t)stream);
+    }
+    return vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
+  }
   if (dtype16 == VMC_BF16) return launch_act<BF16>(g, act, (hipStream_t)stream);
   return launch_act<F16>(g, act, (hipStream_t)stream);
 }
