@@ -77,3 +77,84 @@ def test_tfam_training_trajectory_and_map_parity():
     assert hip_losses[-1] < hip_losses[0]                       # it trains
     assert (hip_val - ora_val).abs().max().item() <= 3e-2       # bf16 training drift over 24 AdamW steps
     assert abs(mAP_hip - mAP_ora) <= 1e-2
+
+
+def test_extractor_to_hdf5_to_tfam_dataset(tmp_path):
+    """extract_embeddings.py:23-119 end to end: decoded frame stacks (.npy, decord is absent offline) -> GPU resize +
+    ViT-B/32 -> HDF5 file in the reference layout (h5lite) -> TFAM HDF5VideoDataset; embeddings vs the CPU oracle."""
+    from oracle import pil_resize as opr
+    from oracle import vit as ovit
+    from vimo_clip_amd import h5lite as h5
+    from vimo_clip_amd.clip_vit import CLIPImageEncoder
+    from vimo_clip_amd.extract_embeddings import create_hdf5_dataset, sample_frame_indices
+    from vimo_clip_amd.TFAM.data.dataset import HDF5VideoDataset
+
+    name, seed = "ViT-B/32", 41
+    enc = CLIPImageEncoder(name, compute_dtype=torch.float16).cuda().eval()
+    sd = synth.vit_state_dict(name, seed)
+    enc.visual.load_state_dict(sd, strict=True)
+    root = tmp_path / "videos"
+    root.mkdir()
+    vids = {"AAAA.mp4": (9, 120, 160), "BBBB.mp4": (4, 224, 224), "CCCC.mp4": (21, 90, 130)}
+    for i, (vid, shape) in enumerate(vids.items()):
+        np.save(str(root / (vid + ".npy")), synth.randint_u8(seed + i, "video", (shape[0], shape[1], shape[2], 3)).numpy())
+    (tmp_path / "ann.txt").write_text("AAAA.mp4 3 17\nBBBB.mp4 0\nMISSING.mp4 5\nCCCC.mp4 139 2 2\n")
+    (tmp_path / "classes.csv").write_text("id,name\n" + "".join(f"{i},c{i}\n" for i in range(140)))
+    out = str(tmp_path / "out" / "ak_val.h5")
+    n = create_hdf5_dataset(str(root), str(tmp_path / "ann.txt"), str(tmp_path / "classes.csv"), out, max_frames=8, encoder=enc,
+                            clip_model_name=name)
+    assert n == 3
+    with h5.File(out, "r") as f:
+        assert f.attrs["num_classes"] == 140 and f.attrs["clip_model"] == name and f.attrs["dataset_name"] == "AnimalKingdom"
+        assert [s.decode() for s in f["video_ids"][:]] == ["AAAA.mp4", "BBBB.mp4", "MISSING.mp4", "CCCC.mp4"]   # :118 keeps every annotation
+        assert f.keys() == ["AAAA.mp4", "BBBB.mp4", "CCCC.mp4", "video_ids"]
+        for i, (vid, shape) in enumerate(vids.items()):
+            idx = sample_frame_indices(shape[0], 8)
+            g = f[vid]
+            assert g.attrs["total_frames"] == len(idx) and g.attrs["original_frames"] == shape[0]
+            assert g["embeddings"].chunks == (1, 512) and g["embeddings"].compression == "gzip"
+            frames = synth.randint_u8(seed + i, "video", (shape[0], shape[1], shape[2], 3))[torch.from_numpy(idx)].permute(0, 3, 1, 2)
+            pre = torch.from_numpy(opr.clip_resize_crop(frames.contiguous().numpy(), 224, "hf").copy())
+            ref = ovit.vit_forward(sd, ovit.normalize_u8(pre), 12)
+            got = torch.from_numpy(g["embeddings"][:])
+            assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()), vid
+        lab = f["CCCC.mp4/labels"][:]
+        assert lab.sum() == 2 and lab[139] == 1 and lab[2] == 1
+    # the file feeds the TFAM dataset (flow stream: the same file stands in, keys without extension are required -> add them)
+    flow = str(tmp_path / "flow.h5")
+    with h5.File(flow, "w") as g, h5.File(out, "r") as f:
+        for vid in vids:
+            g.create_group(vid.split(".")[0]).create_dataset("embeddings", data=f[vid]["embeddings"][:-1])
+    ds = HDF5VideoDataset(out, flow)
+    assert len(ds) == 4                                                     # the reference counts every root key, video_ids included (:25-27)
+    item = ds[2]
+    assert item["video_id"] == "CCCC.mp4" and item["embeddings"].shape == (8, 512) and item["flow_embeddings"].shape == (7, 512)
+
+
+def test_streaming_student_export_matches_oracle(tmp_path):
+    """inference_frame_diff.py:235-410 with the real student (ViT-B/32, f16): chunked streaming export == oracle forward."""
+    from oracle import pil_resize as opr
+    from oracle import vit as ovit
+    from vimo_clip_amd import h5lite as h5
+    from vimo_clip_amd import inference as inf
+    from vimo_clip_amd.models.student_model import FrameDiffStudentModel
+
+    name, seed = "ViT-B/32", 43
+    model = FrameDiffStudentModel(clip_model_name=name, device="cuda", num_classes=140, compute_dtype=torch.float16)
+    sd = synth.student_state_dict(name, seed)
+    model.load_state_dict(sd, strict=True)
+    vdir = tmp_path / "diff_videos"
+    vdir.mkdir()
+    frames = synth.randint_u8(seed, "diff", (13, 96, 128, 3))
+    np.save(str(vdir / "clipA.npy"), frames.numpy())
+    out = str(tmp_path / "student.h5")
+    stats = inf.export_embeddings(inf.FrameDiffVideoDataset(str(vdir)).video_paths, model, out, chunk_size=5, flush_interval_s=0)
+    assert stats["processed"] == 1 and stats["errors"] == 0
+    u8 = frames.permute(0, 3, 1, 2).contiguous()
+    pre = torch.from_numpy(opr.clip_resize_crop(ovit.to_pil_wrap_u8(u8).numpy(), 224, "torchvision").copy())
+    ref = ovit.vit_forward({k[len("visual_encoder."):]: v for k, v in sd.items() if k.startswith("visual_encoder.")}, ovit.normalize_u8(pre), 12)
+    with h5.File(out, "r") as f:
+        d = f["clipA/embeddings"]
+        assert d.shape == (13, 512) and d.chunks == (5, 512) and d.maxshape == (None, 512)
+        got = torch.from_numpy(d[:])
+    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())

@@ -1,0 +1,235 @@
+"""h5lite (native HDF5 subset) against the stock libhdf5 C library, both directions, plus the committed libhdf5-made
+fixture.  Mirrors the call sequences of extract_embeddings.py:50-119, extract_embeddings_mammalNet.py:113-153,
+inference_frame_diff.py:250-310 and the reads of TFAM/data/dataset.py:25-66."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import h5ref  # noqa: E402
+import make_h5_golden  # noqa: E402
+from vimo_clip_amd import h5lite as h5  # noqa: E402
+
+REF = h5ref.load()
+needs_ref = pytest.mark.skipif(REF is None, reason="libhdf5 C library not present: cross-check skipped (fixture test still runs)")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ak_like_libhdf5.h5")
+
+
+def test_reads_libhdf5_fixture():
+    want = make_h5_golden.content()
+    with h5.File(GOLDEN, "r") as f:
+        assert f.keys() == sorted(list(want) + ["grown", "video_ids"])
+        assert f.attrs["num_classes"] == 140 and f.attrs["dataset_name"] == "AnimalKingdom"
+        assert f.attrs["type"] == "val" and f.attrs["clip_model"] == "ViT-B/16"
+        for vid, (emb, lab, tf, of) in want.items():
+            g = f[vid]
+            d = g["embeddings"]
+            assert d.shape == emb.shape and d.dtype == np.float32 and d.chunks == (1, 32) and d.compression == "gzip"
+            assert np.array_equal(d[:], emb) and np.array_equal(d[1:3], emb[1:3]) and np.array_equal(d[-1], emb[-1])
+            assert np.array_equal(g["labels"][:], lab)
+            assert g.attrs["total_frames"] == tf and g.attrs["original_frames"] == of
+        assert [s.decode() for s in f["video_ids"][:]] == list(want)
+        assert list(f["video_ids"].asstr()[:2]) == list(want)[:2]
+        d = f["grown/embeddings"]
+        assert d.shape == (11, 32) and d.maxshape == (None, 32) and d.chunks == (4, 32)
+        assert np.array_equal(d[:, 0], np.repeat([1, 2, 3], [4, 4, 3]).astype(np.float32))
+        assert f["grown"].attrs["skipped_low_ram"] == True  # noqa: E712  (numpy bool)
+        assert "nope" not in f and "grown/embeddings" in f
+        with pytest.raises(KeyError):
+            f["nope"]
+        with pytest.raises(OSError):
+            f.create_group("x")
+
+
+def _write_ak_like(path, n_videos, E=48, t0=3):
+    rng = np.random.default_rng(11)
+    vids = {}
+    with h5.File(path, "w") as hf:
+        hf.attrs["num_classes"] = 140
+        hf.attrs["dataset_name"] = "AnimalKingdom"
+        hf.attrs["type"] = "val"
+        hf.attrs["clip_model"] = "ViT-B/16"
+        for i in range(n_videos):
+            vid = f"v{(i * 7919) % 100003:06d}.mp4"                 # not in sorted order
+            T = t0 + (i * 13) % 90
+            emb = rng.standard_normal((T, E)).astype(np.float32)
+            lab = (rng.random(140) < 0.03).astype(np.float32)
+            g = hf.create_group(vid)
+            g.create_dataset("embeddings", data=emb, compression="gzip", chunks=(1, E))
+            g.create_dataset("labels", data=lab)
+            g.attrs["total_frames"] = T
+            g.attrs["original_frames"] = 30 * T
+            vids[vid] = (emb, lab, T)
+        hf.create_dataset("video_ids", data=np.array(list(vids), dtype=h5.string_dtype()))
+    return vids
+
+
+@needs_ref
+def test_libhdf5_reads_what_h5lite_writes(tmp_path):
+    # 300 groups -> two-level group B-tree (38 symbol nodes > 32); T up to 92 rows of (1,E) chunks -> two-level chunk B-tree
+    p = str(tmp_path / "w.h5")
+    vids = _write_ak_like(p, 300)
+    f = REF.open(p)
+    assert REF.attr(f, "/", "num_classes") == 140 and REF.attr(f, "/", "clip_model") == "ViT-B/16"
+    assert REF.attr(f, "/", "dataset_name") == "AnimalKingdom" and REF.attr(f, "/", "type") == "val"
+    for vid, (emb, lab, T) in vids.items():
+        assert np.array_equal(REF.read(f, f"/{vid}/embeddings"), emb), vid
+        assert np.array_equal(REF.read(f, f"/{vid}/labels"), lab)
+        assert REF.attr(f, f"/{vid}", "total_frames") == T and REF.attr(f, f"/{vid}", "original_frames") == 30 * T
+    assert REF.read(f, "/video_ids") == list(vids)
+    assert not REF.exists(f, "/missing")
+    REF.close(f)
+    with h5.File(p, "r") as hf:                                      # and h5lite reads its own file back
+        assert hf.keys() == sorted(list(vids) + ["video_ids"])
+        k = list(vids)[123]
+        assert np.array_equal(hf[k]["embeddings"][:], vids[k][0])
+
+
+@needs_ref
+def test_h5lite_reads_what_libhdf5_writes(tmp_path):
+    p = str(tmp_path / "r.h5")
+    rng = np.random.default_rng(3)
+    f = REF.create(p)
+    REF.set_attr(f, "num_classes", 12)
+    REF.set_attr(f, "clip_model", "ViT-B/32 é")
+    want = {}
+    for i in range(70):                                               # > 64: group B-tree with several symbol nodes
+        g = REF.group(f, f"vid_{i:03d}")
+        emb = rng.standard_normal((1 + i, 24)).astype(np.float32)
+        REF.lib.H5Dclose(REF.dataset(g, "embeddings", emb, chunks=(1, 24), gzip=4, shuffle=(i % 2 == 0)))
+        REF.lib.H5Dclose(REF.dataset(g, "labels", np.arange(12, dtype=np.float32) * i))
+        REF.lib.H5Dclose(REF.dataset(g, "counts", np.arange(5, dtype=np.int64) - i))
+        REF.set_attr(g, "total_frames", 1 + i)
+        REF.set_attr(g, "fps", 29.97)
+        REF.lib.H5Gclose(g)
+        want[f"vid_{i:03d}"] = emb
+    REF.string_dataset(f, "video_ids", list(want))
+    REF.close(f)
+    with h5.File(p, "r") as hf:
+        assert hf.attrs["num_classes"] == 12 and hf.attrs["clip_model"] == "ViT-B/32 é"
+        assert hf.keys() == sorted(list(want) + ["video_ids"])
+        for i, (k, emb) in enumerate(want.items()):
+            assert np.array_equal(hf[k]["embeddings"][:], emb)
+            assert np.array_equal(hf[k]["labels"][:], np.arange(12, dtype=np.float32) * i)
+            assert np.array_equal(hf[k]["counts"][:], np.arange(5) - i) and hf[k]["counts"].dtype == np.int64
+            assert hf[k].attrs["total_frames"] == 1 + i and abs(hf[k].attrs["fps"] - 29.97) < 1e-12
+        assert [s.decode() for s in hf["video_ids"][:]] == list(want)
+
+
+@needs_ref
+def test_latest_format_is_refused_loudly(tmp_path):
+    p = str(tmp_path / "latest.h5")
+    f = REF.create(p, latest=True)
+    REF.lib.H5Gclose(REF.group(f, "g"))
+    REF.close(f)
+    with pytest.raises(NotImplementedError):
+        h5.File(p, "r")
+
+
+def _stream_video(hf, vid, blocks, E, chunk_rows):
+    """inference_frame_diff.py:250-299 / extract_embeddings_mammalNet.py:113-142."""
+    group = hf.require_group(vid)
+    if "embeddings" in group:
+        return group["embeddings"].shape
+    dset = group.create_dataset("embeddings", shape=(0, E), maxshape=(None, E), chunks=(chunk_rows, E), dtype="float32", compression="gzip")
+    for b in blocks:
+        old_n = dset.shape[0]
+        dset.resize((old_n + b.shape[0], E))
+        dset[old_n:old_n + b.shape[0], :] = b
+        hf.flush()
+    return dset.shape
+
+
+def test_extendable_append_resume_and_commit_consistency(tmp_path):
+    p = str(tmp_path / "s.h5")
+    rng = np.random.default_rng(5)
+    E = 16
+    data = {f"clip{i}": [rng.standard_normal((n, E)).astype(np.float32) for n in (32, 32, 7)] for i in range(5)}
+    with h5.File(p, "a") as hf:
+        for vid in list(data)[:3]:
+            _stream_video(hf, vid, data[vid], E, 32)
+        hf.flush()
+        shutil.copy(p, str(tmp_path / "snapshot.h5"))               # what a crash right here would leave behind
+        g = hf.require_group("clip3")
+        g.attrs["error"] = "decode failed"                            # inference_frame_diff.py:402-404
+        d = hf["clip0/embeddings"]
+        d.resize((d.shape[0] + 5, E))
+        d[-5:] = 9.0                                                   # partial last chunk: read-modify-write
+        # not flushed yet: the snapshot must still be the committed tree
+    with h5.File(str(tmp_path / "snapshot.h5"), "r") as snap:
+        assert snap.keys() == ["clip0", "clip1", "clip2"]
+        assert np.array_equal(snap["clip0/embeddings"][:], np.concatenate(data["clip0"]))
+    with h5.File(p, "a") as hf:                                       # resumed run
+        assert hf["clip3"].attrs["error"] == "decode failed" and "embeddings" not in hf["clip3"]
+        assert hf["clip0/embeddings"].shape == (76, E) and np.all(hf["clip0/embeddings"][71:] == 9.0)
+        for vid in data:
+            if vid == "clip3":
+                continue
+            shape = _stream_video(hf, vid, data[vid], E, 32)          # existing ones are skipped
+            assert shape[1] == E
+        empty = hf.require_group("nothing")
+        empty.create_dataset("embeddings", shape=(0, 0), maxshape=(None, 0), dtype="float32")   # :307
+        hf["clip1/embeddings"].resize(40, axis=0)                     # shrink: second chunk partly kept, third dropped
+    with h5.File(p, "r") as hf:
+        assert hf.keys() == ["clip0", "clip1", "clip2", "clip3", "clip4", "nothing"]
+        assert np.array_equal(hf["clip4/embeddings"][:], np.concatenate(data["clip4"]))
+        assert np.array_equal(hf["clip1/embeddings"][:], np.concatenate(data["clip1"])[:40])
+        assert hf["nothing/embeddings"].shape == (0, 0)
+        assert hf["clip2/embeddings"].maxshape == (None, E)
+    if REF is not None:
+        f = REF.open(p)
+        assert np.array_equal(REF.read(f, "/clip4/embeddings"), np.concatenate(data["clip4"]))
+        assert np.array_equal(REF.read(f, "/clip0/embeddings")[:71], np.concatenate(data["clip0"]))
+        assert REF.maxshape(f, "/clip2/embeddings") == (None, E)
+        assert REF.attr(f, "/clip3", "error") == "decode failed"
+        REF.close(f)
+        f = REF.open(p, rw=True)                                       # libhdf5 can keep appending to our file
+        d = REF.lib.H5Dopen2(f, b"/clip2/embeddings", 0)
+        REF.append_rows(d, np.full((3, E), 5.0, np.float32))
+        REF.lib.H5Dclose(d)
+        REF.close(f)
+        with h5.File(p, "r") as hf:
+            assert hf["clip2/embeddings"].shape == (74, E) and np.all(hf["clip2/embeddings"][71:] == 5.0)
+
+
+def test_space_is_reused_across_commits(tmp_path):
+    p = str(tmp_path / "reuse.h5")
+    with h5.File(p, "w") as hf:
+        for i in range(200):
+            hf.create_group(f"g{i:04d}").attrs["total_frames"] = i
+            if i % 10 == 9:
+                hf.flush()
+    size = os.path.getsize(p)
+    assert size < 400_000, size                                        # 20 commits of a 200-entry root table, not 20 copies
+    with h5.File(p, "r") as hf:
+        assert len(hf) == 200 and hf["g0150"].attrs["total_frames"] == 150
+
+
+def test_api_errors(tmp_path):
+    p = str(tmp_path / "e.h5")
+    with pytest.raises(FileNotFoundError):
+        h5.File(p, "r")
+    with h5.File(p, "w") as hf:
+        hf.create_dataset("a", data=np.arange(6, dtype=np.float32).reshape(2, 3))
+        with pytest.raises(ValueError):
+            hf.create_dataset("a", data=np.zeros(2, np.float32))
+        with pytest.raises(TypeError):
+            hf["a"].resize((4, 3))                                     # contiguous datasets do not resize
+        with pytest.raises(ValueError):
+            hf.create_dataset("z", shape=(4,), dtype="float32", compression="lzf")
+        d = hf.create_dataset("b", shape=(2, 3), maxshape=(4, 3), dtype="int32")
+        with pytest.raises(ValueError):
+            d.resize((5, 3))
+        d[...] = 7
+        d[0, 1] = 3
+    with h5.File(p, "r") as hf:
+        assert np.array_equal(hf["a"][:], np.arange(6, dtype=np.float32).reshape(2, 3)) and hf["a"][1, 2] == 5.0
+        assert np.array_equal(hf["b"][:], [[7, 3, 7], [7, 7, 7]])
+    with open(str(tmp_path / "junk.h5"), "wb") as fh:
+        fh.write(b"not an hdf5 file at all")
+    with pytest.raises(OSError):
+        h5.File(str(tmp_path / "junk.h5"), "r")
+    assert h5.is_hdf5(p) and not h5.is_hdf5(str(tmp_path / "junk.h5"))

@@ -18,7 +18,7 @@ class HDF5VideoDataset(Dataset):
     """TFAM/data/dataset.py:15-73: RGB group by key, flow group by ``key.split('.')[0]``."""
 
     def __init__(self, hdf5_path, flow_path, transform=None, num_frames=None, max_frames=None):
-        import h5py  # noqa: F401  (absent offline; no silent fallback)
+        from ... import h5lite as h5py        # native reader of the reference's HDF5 layout
         self.hdf5_path, self.flow_path, self.transform = hdf5_path, flow_path, transform
         self.num_frames, self.max_frames = num_frames, max_frames
 
@@ -35,7 +35,7 @@ class HDF5VideoDataset(Dataset):
         return len(self.keys)
 
     def __getitem__(self, idx):
-        import h5py
+        from ... import h5lite as h5py
         video_id = self.keys[idx]
         with h5py.File(self.hdf5_path, "r") as f:
             embeddings = torch.from_numpy(f[video_id]["embeddings"][:])

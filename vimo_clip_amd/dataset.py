@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -63,12 +64,27 @@ def slice_flow_segment(flow_video: torch.Tensor, start_idx: int, seg_len: int, s
     return seq
 
 
+def read_video_frames(path: str) -> torch.Tensor:
+    """[T,H,W,3] u8 frames of one flow / frame-diff video (dataset.py:95 ``io.read_video(..., pts_unit="sec")``).
+    Decoding is host-side I/O outside the hot path: torchvision.io when it is installed; offline, a ``.npy`` file of the
+    decoded frames (same stem, or the path itself) is read instead.  Neither present -> the ImportError is raised."""
+    stem = os.path.splitext(path)[0]
+    for cand in (path if path.endswith(".npy") else None, path + ".npy", stem + ".npy"):
+        if cand and os.path.exists(cand):
+            arr = np.load(cand, mmap_mode="r")
+            if arr.ndim != 4 or arr.shape[-1] != 3 or arr.dtype != np.uint8:
+                raise ValueError(f"{cand}: expected [T,H,W,3] uint8 frames, got {arr.shape} {arr.dtype}")
+            return torch.from_numpy(np.array(arr))
+    import torchvision.io as io
+    return io.read_video(path, pts_unit="sec")[0]
+
+
 class HDF5VideoDataset(Dataset):
     """Same constructor, item keys and semantics as the reference class (dataset.py:8-134)."""
 
     def __init__(self, clip_embeddings_dir, flow_videos_dir, sequence_length=2, transform=None):
         super().__init__()
-        import h5py  # noqa: F401  (ImportError here is intentional: no silent fallback)
+        from . import h5lite as h5py          # native reader of the reference's HDF5 layout (h5py itself is not needed)
         self.hdf5_path, self.flow_videos_dir = clip_embeddings_dir, flow_videos_dir
         self.sequence_length, self.transform = sequence_length, transform
         with h5py.File(self.hdf5_path, "r") as f:
@@ -79,8 +95,7 @@ class HDF5VideoDataset(Dataset):
         return len(self.segments)
 
     def __getitem__(self, idx):
-        import h5py
-        import torchvision.io as io
+        from . import h5lite as h5py
         video_id, start_idx, seg_len = self.segments[idx]
         with h5py.File(self.hdf5_path, "r") as f:
             group = f[video_id]
@@ -89,8 +104,7 @@ class HDF5VideoDataset(Dataset):
         rgb_seq = slice_rgb_segment(embeddings, start_idx, seg_len, self.sequence_length)
         if self.transform:
             rgb_seq = self.transform(rgb_seq)
-        flow_video, _, _ = io.read_video(os.path.join(self.flow_videos_dir, video_id), pts_unit="sec")
-        flow_video = flow_video.permute(0, 3, 1, 2)
+        flow_video = read_video_frames(os.path.join(self.flow_videos_dir, video_id)).permute(0, 3, 1, 2)
         flow_seq = slice_flow_segment(flow_video, start_idx, seg_len, self.sequence_length)
         return {"video_id": video_id, "rgb_emb": rgb_seq, "flow_frames": flow_seq, "labels": labels}
 
