@@ -242,6 +242,13 @@ int vmc_distill_loss(const float* student, const float* teacher, float* loss, fl
  * nn.BCEWithLogitsLoss of TFAM/train_and_eval.py:58).  logits/targets f32 [n]; mean over n. */
 int vmc_bce_loss(const float* logits, const float* targets, float* loss, float* dlogits, int n, float pos_weight,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* Softmax cross entropy, mean over rows — nn.CrossEntropyLoss() of the MammalNet (single-label) variants:
+ * train_frame_diff_mn.py:82,102 passes class indices (``labels.argmax(dim=1)``), TFAM/train_and_eval_frame_diff_MN.py:59,83
+ * passes the float one-hot rows themselves (probability targets).  Exactly one of target_index (int64 [rows]) and
+ * target_prob (f32 [rows,C]) is non-NULL.  logits f32 [rows,C]; loss f32[1]; dlogits f32 [rows,C] or NULL;
+ * workspace >= vmc_loss_workspace_bytes(rows). */
+int vmc_cross_entropy_loss(const float* logits, const long long* target_index, const float* target_prob, float* loss,
+                           float* dlogits, int rows, int C, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K15 — fused Adam / AdamW over one flat fp32 buffer (train.py:66; TFAM/train_and_eval.py:53).

@@ -61,6 +61,16 @@ def classification_loss(pred, targets, positive_weight=None):
     return loss.mean()
 
 
+def cross_entropy_loss(pred, targets):
+    """nn.CrossEntropyLoss() (mean) of the MammalNet variants: train_frame_diff_mn.py:82,102 (class indices) and
+    TFAM/train_and_eval_frame_diff_MN.py:59,83 (float one-hot rows = probability targets).  Written out (log-softmax) so
+    the oracle does not lean on the fused torch op it checks."""
+    logp = pred - torch.logsumexp(pred, dim=1, keepdim=True)
+    if targets.is_floating_point():
+        return -(targets * logp).sum(dim=1).mean()
+    return -logp.gather(1, targets.view(-1, 1).long()).mean()
+
+
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False):
     """torch.optim.Adam (train.py:66) / AdamW (TFAM/train_and_eval.py:53) single-tensor update,
     PyTorch default formulation: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""

@@ -154,3 +154,38 @@ def test_cosine_schedule_closed_form():
         ref.step()
         assert math.isclose(sch.get_last_lr()[0], ref.get_last_lr()[0], rel_tol=1e-9)
         assert math.isclose(sch.get_last_lr()[0], otfam.cosine_lr(e, 30), rel_tol=1e-12)
+
+
+def test_accuracy_metric_and_task_objects():
+    import torch
+    from vimo_clip_amd.metrics import Accuracy
+    from vimo_clip_amd.TFAM.train_and_eval import Config, task_objects
+    m = Accuracy(num_classes=4)
+    logits = torch.tensor([[0.1, 2.0, 0.0, -1.0], [3.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.5, 0.4], [0.0, 0.0, 0.0, 9.0]])
+    onehot = torch.eye(4)[[1, 2, 2, 3]].to(torch.int)
+    m.update(logits[:2], onehot[:2])
+    m.update(logits[2:], onehot[2:])
+    assert abs(float(m.compute()) - 0.75) < 1e-7
+    m.reset()
+    m.update(logits, torch.tensor([1, 0, 2, 3]))                      # index targets are accepted too
+    assert float(m.compute()) == 1.0
+    crit, metric = task_objects(Config(task="singlelabel", num_classes=4))
+    assert isinstance(metric, Accuracy) and crit.__name__ == "cross_entropy_loss"
+    import pytest
+    with pytest.raises(ValueError):
+        task_objects(Config(task="ranking"))
+
+
+def test_yaml_config_and_sweep(tmp_path):
+    from vimo_clip_amd.TFAM import sweep
+    from vimo_clip_amd.TFAM.train_and_eval import Config
+    paths = sweep.write_sweep(str(tmp_path / "cfg"), base={"training": {"epochs": 2}, "data": {"num_classes": 12}})
+    assert len(paths) == 20                                             # 5 fusion modes x PE x 2 dropout pairs
+    cfgs = [Config.from_yaml(p) for p in paths]
+    assert {(c.use_cross_attn, c.use_only_rgb, c.use_only_flow, c.concat_dim) for c in cfgs} == {
+        (True, False, False, 1), (False, False, False, 1), (False, False, False, -1), (False, True, False, 1), (False, False, True, 1)}
+    assert all(c.epochs == 2 and c.num_classes == 12 and c.motion_key == "frame_diff" and c.lr == 1e-4 for c in cfgs)
+    (tmp_path / "bad.yaml").write_text("training: {mode: both}\nlogging: {}\ndata: {}\nmodel: {}\n")
+    import pytest
+    with pytest.raises(KeyError):
+        Config.from_yaml(str(tmp_path / "bad.yaml"))

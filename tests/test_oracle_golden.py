@@ -99,3 +99,16 @@ def test_to_pil_wrap_identity():
     w = vit.to_pil_wrap_u8(v)
     assert torch.equal(w.to(torch.int64), (256 - v.to(torch.int64)) % 256)
     assert np.array_equal((v.numpy().astype(np.float32) * 255).astype(np.int64) % 256, w.numpy())
+
+
+def test_cross_entropy_restatement_vs_torch():
+    # the reference's callee is torch's nn.CrossEntropyLoss itself (train_frame_diff_mn.py:82, TFAM ..._MN.py:59)
+    import torch
+    from oracle import student as ostudent
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(9, 12, generator=g) * 4
+    t = torch.randint(0, 12, (9,), generator=g)
+    assert torch.allclose(ostudent.cross_entropy_loss(x, t), torch.nn.CrossEntropyLoss()(x, t), atol=1e-6)
+    y = torch.nn.functional.one_hot(t, 12).float()
+    y[0] = torch.softmax(torch.randn(12, generator=g), 0)          # a soft row
+    assert torch.allclose(ostudent.cross_entropy_loss(x, y), torch.nn.CrossEntropyLoss()(x, y), atol=1e-6)

@@ -15,20 +15,61 @@ import numpy as np
 import torch
 
 from .. import parallel, synth
-from ..losses import bce_with_logits_loss
-from ..metrics import MultilabelAveragePrecision
+from ..losses import bce_with_logits_loss, cross_entropy_loss
+from ..metrics import Accuracy, MultilabelAveragePrecision
 from ..optim import CosineAnnealingLR, FusedAdam, GradArena
 from .data.dataset import SyntheticEmbeddingDataset, collate_fn_pad
 from .models import AMO_CLIP
 
 
 class Config:
+    """The attribute bag the reference fills from its YAML (train_and_eval_frame_diff_AK.py:311-365), plus two switches
+    for the variants that are separate scripts upstream: ``task`` ("multilabel": BCE + micro-mAP, Animal Kingdom;
+    "singlelabel": CrossEntropy + Accuracy, MammalNet, train_and_eval_frame_diff_MN.py:49,59) and ``motion_key``
+    ("flow" / "frame_diff": the batch keys ``{motion_key}_embeddings`` and ``mask_{motion_key}``)."""
+
     def __init__(self, **kw):
-        self.mode, self.seed, self.lr, self.epochs, self.batch_size = "both", 49, 1e-4, 30, 8
+        self.mode, self.seed, self.lr, self.epochs, self.batch_size, self.num_workers = "both", 49, 1e-4, 30, 8, 4
         self.num_classes, self.d_model, self.nhead, self.num_layers, self.dim_feedforward = 140, 512, 8, 4, 2048
         self.use_cross_attention, self.use_only_rgb, self.use_only_flow, self.use_pe, self.concat_dim = True, False, False, False, 1
-        self.dropout, self.mlp_dropout, self.device, self.checkpoint_dir = 0.1, 0.1, "cuda", "checkpoints"
+        self.dropout, self.mlp_dropout, self.device, self.checkpoint_dir, self.log_dir = 0.1, 0.1, "cuda", "checkpoints", "logs"
+        self.task, self.motion_key = "multilabel", "flow"
+        self.class_names_dir = self.train_dataset_path = self.val_dataset_path = self.frame_diff_dataset_path = None
         self.__dict__.update(kw)
+
+    @property
+    def use_cross_attn(self):      # the reference stores model.use_cross_attention under this name (:359)
+        return self.use_cross_attention
+
+    @classmethod
+    def from_yaml(cls, path, **overrides):
+        """Sections ``training / logging / data / model`` with the reference's keys (:320-365).  Keys the reference
+        requires raise KeyError when missing, as ``cfg[...]`` does there."""
+        import yaml
+        with open(path, "r") as f:
+            cfg = yaml.safe_load(f)
+        t, lg, d, m = cfg["training"], cfg["logging"], cfg["data"], cfg["model"]
+        kw = dict(mode=t["mode"], seed=t["seed"], lr=float(t["lr"]), epochs=t["epochs"], batch_size=t["batch_size"],
+                  num_workers=t["num_workers"], device=t["device"], log_dir=lg["log_dir"], checkpoint_dir=lg["checkpoint_dir"],
+                  num_classes=d["num_classes"], class_names_dir=d["class_names_dir"], train_dataset_path=d["train_dataset_path"],
+                  val_dataset_path=d["val_dataset_path"],
+                  frame_diff_dataset_path=d.get("frame_diff_dataset_path", d.get("flow_dataset_path")),
+                  d_model=m["d_model"], nhead=m["nhead"], num_layers=m["num_layers"], dim_feedforward=m["dim_feedforward"],
+                  use_cross_attention=m["use_cross_attention"], concat_dim=m["concat_dim"], dropout=m["dropout"],
+                  mlp_dropout=m["mlp_dropout"], use_pe=m["use_pe"], use_only_rgb=m["use_only_rgb"], use_only_flow=m["use_only_flow"])
+        if "frame_diff_dataset_path" in d:
+            kw["motion_key"] = "frame_diff"
+        kw.update(overrides)
+        return cls(**kw)
+
+
+def task_objects(config):
+    """(criterion, metric) of the task: BCE-with-logits + micro mAP (:49,58) or CrossEntropy + Accuracy (MN :49,59)."""
+    if config.task == "multilabel":
+        return bce_with_logits_loss, MultilabelAveragePrecision(num_labels=config.num_classes, average="micro")
+    if config.task == "singlelabel":
+        return cross_entropy_loss, Accuracy(num_classes=config.num_classes)
+    raise ValueError(f"Unsupported task '{config.task}'. Choose 'multilabel' or 'singlelabel'.")
 
 
 def set_seed(seed: int = 0):
@@ -38,32 +79,35 @@ def set_seed(seed: int = 0):
     torch.manual_seed(seed)
 
 
-def batches(dataset, batch_size, rank=0, world=1, drop_last=True, order=None):
+def batches(dataset, batch_size, rank=0, world=1, drop_last=True, order=None, motion_key="flow"):
     """Contiguous per-rank shard, then fixed-size batches through collate_fn_pad (the DataLoader of :374,398)."""
     idx = list(range(len(dataset))) if order is None else list(order)
     lo, hi = parallel.shard_range(len(idx), rank, world, drop_last=True)
     idx = idx[lo:hi]
     for s in range(0, len(idx) - (batch_size - 1 if drop_last else 0), batch_size):
-        yield collate_fn_pad([dataset[i] for i in idx[s:s + batch_size]])
+        yield collate_fn_pad([dataset[i] for i in idx[s:s + batch_size]], motion_key=motion_key)
+
+
+def _model_forward(model, batch, config):
+    dev, mk = config.device, config.motion_key
+    return model(batch["embeddings"].to(dev), batch[f"{mk}_embeddings"].to(dev), mask_rgb=batch["mask_rgb"].to(dev),
+                 mask_flow=batch[f"mask_{mk}"].to(dev))
 
 
 class ModelTrainer:
     def __init__(self, model, train_set, val_set, config, rank=0, world=1):
         self.model, self.train_set, self.val_set, self.config, self.rank, self.world = model, train_set, val_set, config, rank, world
-        self.mAP_metric = MultilabelAveragePrecision(num_labels=config.num_classes, average="micro")
+        self.criterion, self.mAP_metric = task_objects(config)       # the reference keeps the name mAP_metric / metric for both tasks
+        self.metric = self.mAP_metric
         self.best_val_mAP, self.best_val_loss = 0.0, float("inf")
         self.arena = GradArena(model.used_parameters())
         parallel.broadcast_parameters(self.arena.flat_param)
         self.optimizer = FusedAdam(self.arena, lr=1e-4, weight_decay=0.1, decoupled=True)       # lr hard-coded as :53
         self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.epochs, eta_min=1e-6)
         self.reducer = parallel.GradientAllReducer(self.arena.flat_grad)
-        self.criterion = bce_with_logits_loss
 
     def _forward(self, batch):
-        dev = self.config.device
-        out = self.model(batch["embeddings"].to(dev), batch["flow_embeddings"].to(dev), mask_rgb=batch["mask_rgb"].to(dev),
-                         mask_flow=batch["mask_flow"].to(dev))
-        return out, batch["labels"].to(dev)
+        return _model_forward(self.model, batch, self.config), batch["labels"].to(self.config.device)
 
     def train_epoch(self, epoch):
         self.model.train()
@@ -71,7 +115,7 @@ class ModelTrainer:
         total, n = torch.zeros((), device=self.config.device), 0
         g = torch.Generator().manual_seed(self.config.seed + epoch)
         order = torch.randperm(len(self.train_set), generator=g).tolist()
-        for batch in batches(self.train_set, self.config.batch_size, self.rank, self.world, order=order):
+        for batch in batches(self.train_set, self.config.batch_size, self.rank, self.world, order=order, motion_key=self.config.motion_key):
             output, labels = self._forward(batch)
             loss = self.criterion(output, labels)
             loss.backward()
@@ -87,7 +131,7 @@ class ModelTrainer:
         self.mAP_metric.reset()
         total, n = torch.zeros((), device=self.config.device), 0
         with torch.no_grad():
-            for batch in batches(self.val_set, self.config.batch_size, self.rank, self.world):
+            for batch in batches(self.val_set, self.config.batch_size, self.rank, self.world, motion_key=self.config.motion_key):
                 output, labels = self._forward(batch)
                 total += self.criterion(output, labels)
                 n += 1
@@ -119,18 +163,17 @@ class ModelTrainer:
 class ModelTester:
     def __init__(self, model, test_set, config, rank=0, world=1):
         self.model, self.test_set, self.config, self.rank, self.world = model, test_set, config, rank, world
-        self.mAP_metric = MultilabelAveragePrecision(num_labels=config.num_classes, average="micro")
+        _, self.mAP_metric = task_objects(config)
 
     def evaluate(self, k=5):
         """sigmoid top-k predictions + micro mAP (:193-248)."""
         self.model.eval()
         results, dev = {}, self.config.device
         with torch.no_grad():
-            for batch in batches(self.test_set, self.config.batch_size, self.rank, self.world):
-                out = self.model(batch["embeddings"].to(dev), batch["flow_embeddings"].to(dev), mask_rgb=batch["mask_rgb"].to(dev),
-                                 mask_flow=batch["mask_flow"].to(dev))
+            for batch in batches(self.test_set, self.config.batch_size, self.rank, self.world, motion_key=self.config.motion_key):
+                out = _model_forward(self.model, batch, self.config)
                 self.mAP_metric.update(out, batch["labels"].to(dev).to(torch.int))
-                probs = torch.sigmoid(out)
+                probs = torch.sigmoid(out) if self.config.task == "multilabel" else torch.softmax(out, dim=1)
                 top = torch.topk(probs, k, dim=1)
                 for vid, idx, pr in zip(batch["video_id"], top.indices.tolist(), top.values.tolist()):
                     results[vid] = {"top_classes": idx, "top_probs": pr}
@@ -147,30 +190,72 @@ def _labels_from_annotations(path, num_classes, limit=None):
     return lab
 
 
-def main():
-    ap = argparse.ArgumentParser(description="TFAM train/eval on MI355X (synthetic embeddings over real or synthetic labels)")
+def build_model(cfg):
+    """AMO_CLIP(...) exactly as :379-393 builds it from the config."""
+    return AMO_CLIP(d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers, dim_feedforward=cfg.dim_feedforward,
+                    num_classes=cfg.num_classes, use_only_rgb=cfg.use_only_rgb, use_only_flow=cfg.use_only_flow, use_pe=cfg.use_pe,
+                    use_cross_attention=cfg.use_cross_attention, concat_dim=cfg.concat_dim, dropout=cfg.dropout,
+                    mlp_dropout=cfg.mlp_dropout, device=cfg.device).to(cfg.device)
+
+
+def build_datasets(cfg, limit=2048, train_annotations=None, val_annotations=None):
+    """HDF5 datasets when the config names existing files (:375,396), otherwise synthetic embeddings over real or
+    synthetic label rows (there are no AK / MammalNet embeddings offline)."""
+    import os
+    paths = (cfg.train_dataset_path, cfg.val_dataset_path, cfg.frame_diff_dataset_path)
+    if all(p and os.path.exists(p) for p in paths):
+        from .data import dataset as dflow
+        from .data import dataset_frame_diff as ddiff
+        D = ddiff.HDF5VideoDataset if cfg.motion_key == "frame_diff" else dflow.HDF5VideoDataset
+        return D(cfg.train_dataset_path, cfg.frame_diff_dataset_path), D(cfg.val_dataset_path, cfg.frame_diff_dataset_path)
+    C = cfg.num_classes
+    if cfg.task == "singlelabel":
+        one_hot = lambda seed, n: torch.nn.functional.one_hot(synth.randint(seed, "cls", (n,), 0, C), C).float()
+        tl, vl = one_hot(1, limit), one_hot(2, limit // 4)
+    else:
+        tl = _labels_from_annotations(train_annotations, C, limit) if train_annotations else synth.multi_hot_labels(1, "tr", limit, C)
+        vl = _labels_from_annotations(val_annotations, C, limit // 4) if val_annotations else synth.multi_hot_labels(2, "va", limit // 4, C)
+    return (SyntheticEmbeddingDataset(tl, cfg.d_model, seed=5, motion_key=cfg.motion_key, class_seed=5),
+            SyntheticEmbeddingDataset(vl, cfg.d_model, seed=6, motion_key=cfg.motion_key, class_seed=5))
+
+
+def run(cfg, rank=0, world=1, limit=2048, train_annotations=None, val_annotations=None):
+    """The ``__main__`` block of the reference (:367-408): train and / or test according to ``cfg.mode``."""
+    set_seed(cfg.seed)
+    train_set, val_set = build_datasets(cfg, limit, train_annotations, val_annotations)
+    model = build_model(cfg)
+    model.set_dropout_seed(cfg.seed * 1000 + rank)
+    out = {"world": world, "task": cfg.task}
+    if cfg.mode in ("train", "both"):
+        out["best_val_metric"] = ModelTrainer(model, train_set, val_set, cfg, rank, world).train()
+    if cfg.mode in ("test", "both"):
+        out["test_metric"], _ = ModelTester(model, val_set, cfg, rank, world).evaluate()
+    return out
+
+
+def main(default_task="multilabel", default_motion_key="flow"):
+    ap = argparse.ArgumentParser(description="TFAM train/eval on MI355X (HDF5 embeddings, or synthetic ones over real / synthetic labels)")
+    ap.add_argument("--config", default=None, help="YAML in the reference's schema (TFAM/cfg_AK/*.yaml)")
+    ap.add_argument("--task", default=default_task, choices=["multilabel", "singlelabel"])
     ap.add_argument("--train-annotations", default=None, help="train_multi.txt (video_id class ids...); synthetic labels if omitted")
     ap.add_argument("--val-annotations", default=None)
     ap.add_argument("--limit", type=int, default=2048)
-    ap.add_argument("--epochs", type=int, default=3)
-    ap.add_argument("--batch-size", type=int, default=8)
-    ap.add_argument("--d-model", type=int, default=512)
-    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--d-model", type=int, default=None)
+    ap.add_argument("--dropout", type=float, default=None)
     args = ap.parse_args()
     rank, world, local = parallel.init_from_env()
-    cfg = Config(epochs=args.epochs, batch_size=args.batch_size, d_model=args.d_model, dropout=args.dropout, mlp_dropout=args.dropout,
-                 device=f"cuda:{local}")
-    set_seed(cfg.seed)
-    tl = _labels_from_annotations(args.train_annotations, 140, args.limit) if args.train_annotations else synth.multi_hot_labels(1, "tr", args.limit, 140)
-    vl = _labels_from_annotations(args.val_annotations, 140, args.limit // 4) if args.val_annotations else synth.multi_hot_labels(2, "va", args.limit // 4, 140)
-    train_set, val_set = SyntheticEmbeddingDataset(tl, cfg.d_model, seed=5), SyntheticEmbeddingDataset(vl, cfg.d_model, seed=6)
-    model = AMO_CLIP(d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers, dim_feedforward=cfg.dim_feedforward,
-                     num_classes=cfg.num_classes, dropout=cfg.dropout, mlp_dropout=cfg.mlp_dropout, device=cfg.device).to(cfg.device)
-    model.set_dropout_seed(cfg.seed * 1000 + rank)
-    best = ModelTrainer(model, train_set, val_set, cfg, rank, world).train()
-    mAP, _ = ModelTester(model, val_set, cfg, rank, world).evaluate()
+    over = {k: v for k, v in dict(epochs=args.epochs, batch_size=args.batch_size, d_model=args.d_model, dropout=args.dropout,
+                                  mlp_dropout=args.dropout).items() if v is not None}
+    over.update(task=args.task, device=f"cuda:{local}")
+    if args.config:
+        cfg = Config.from_yaml(args.config, **over)
+    else:
+        cfg = Config(**{**dict(epochs=3, motion_key=default_motion_key), **over})
+    res = run(cfg, rank, world, args.limit, args.train_annotations, args.val_annotations)
     if rank == 0:
-        print(json.dumps({"best_val_mAP": best, "test_mAP": mAP, "world": world}))
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

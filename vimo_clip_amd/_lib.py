@@ -61,6 +61,7 @@ SIGNATURES = {
     "vmc_loss_workspace_bytes": (Z, [I]),
     "vmc_distill_loss": (I, [P, P, P, P, I, I, I, Z, I, P, Z, P]),
     "vmc_bce_loss": (I, [P, P, P, P, I, F, P, Z, P]),
+    "vmc_cross_entropy_loss": (I, [P, P, P, P, P, I, I, P, Z, P]),
     "vmc_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, I, F, P]),
     "vmc_sumsq": (I, [P, Z, P, P]),
 }

@@ -98,18 +98,31 @@ class LinearFn(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         if b is not None and rows is not None:
             b = b[rows[0]:rows[1]]
+        Nw = w16.shape[0]
+        if Nw % 8:                                 # odd output width (e.g. a 10- or 12-class head): zero rows up to 8n
+            if res is not None:
+                raise ValueError("LinearFn: a residual needs an output width that is a multiple of 8")
+            Np = (Nw + 7) // 8 * 8
+            wp = torch.zeros((Np, w16.shape[1]), dtype=dt16, device=x.device)
+            wp[:Nw].copy_(w16)
+            w16 = wp
+            if b is not None:
+                bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+                bp[:Nw].copy_(b)
+                b = bp
+        crop = (lambda t: t[:, :Nw].contiguous()) if w16.shape[0] != Nw else (lambda t: t)
         z = None
         if act != ACT_NONE:
             if res is not None:
                 raise ValueError("LinearFn: activation and residual are not combined on this path")
             if inference:                          # no graph is being built: activation fused into the GEMM epilogue
-                return ops.linear(x, w16, bias=b, act=act, out_dtype=torch.float32 if out_f32 else dt16)
-            z = ops.linear(x, w16, bias=b)
+                return crop(ops.linear(x, w16, bias=b, act=act, out_dtype=torch.float32 if out_f32 else dt16))
+            z = crop(ops.linear(x, w16, bias=b))
             y = ops.act_fwd(z, act)
             if out_f32:
                 y = ops.cast32(y)
         else:
-            y = ops.linear(x, w16, bias=b, res=res, out_dtype=torch.float32 if out_f32 else dt16)
+            y = crop(ops.linear(x, w16, bias=b, res=res, out_dtype=torch.float32 if out_f32 else dt16))
         ctx.save_for_backward(x, z)
         ctx.weight, ctx.bias, ctx.act = weight, bias, act
         ctx.has_res = res is not None
@@ -183,7 +196,12 @@ class LinearFn(torch.autograd.Function):
                     dw = dwp.contiguous()
         db = None
         if bias is not None and bias.requires_grad:
-            db = ops.colsum(dz)
+            if N % 8:                                                                   # odd width: column sums of a padded copy
+                dzc = torch.zeros((M, (N + 7) // 8 * 8), dtype=dt16, device=dz.device)
+                dzc[:, :N].copy_(dz)
+                db = ops.colsum(dzc)[:N].contiguous()
+            else:
+                db = ops.colsum(dz)
             if rows is not None:
                 slot = getattr(bias, "_vmc_grad", None)
                 if slot is not None:

@@ -112,6 +112,61 @@ extern "C" int vmc_bce_loss(const float* logits, const float* targets, float* lo
   return 0;
 }
 
+// ---- softmax cross entropy (nn.CrossEntropyLoss, mean over rows) ------------------------------------
+// One wave per row: m = max x, lse = m + log sum exp(x - m).  Index targets: l = lse - x[t].  Probability targets
+// (float [rows, C], what the MammalNet TFAM loop passes): l = sum_c y_c (lse - x_c).  d l / d x_c = softmax_c * sum(y) - y_c.
+__global__ void __launch_bounds__(256) ce_rows_kernel(const float* __restrict__ x, const long long* __restrict__ tidx,
+                                                      const float* __restrict__ tprob, float* __restrict__ row_loss,
+                                                      float* __restrict__ dx, int rows, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+  m = wave_max(m);
+  float se = 0.f, ysum = 0.f, yx = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    se += expf(xr[c] - m);
+    if (tprob) {
+      const float y = tprob[(size_t)row * C + c];
+      ysum += y;
+      yx += y * xr[c];
+    }
+  }
+  se = wave_sum(se);
+  const float lse = m + logf(se);
+  long long t = -1;
+  if (tprob) {
+    ysum = wave_sum(ysum);
+    yx = wave_sum(yx);
+  } else {
+    t = tidx[row];
+    ysum = 1.0f;
+    yx = (t >= 0 && t < C) ? xr[t] : 0.0f;
+  }
+  if (lane == 0) row_loss[row] = ysum * lse - yx;
+  if (dx) {
+    const float inv = 1.0f / (float)rows, rse = 1.0f / se;
+    for (int c = lane; c < C; c += 64) {
+      const float y = tprob ? tprob[(size_t)row * C + c] : (c == t ? 1.0f : 0.0f);
+      dx[(size_t)row * C + c] = (expf(xr[c] - m) * rse * ysum - y) * inv;
+    }
+  }
+}
+
+extern "C" int vmc_cross_entropy_loss(const float* logits, const long long* target_index, const float* target_prob, float* loss,
+                                      float* dlogits, int rows, int C, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!logits || !loss || !workspace || rows <= 0 || C <= 0) return VMC_E_ARG;
+  if ((target_index == nullptr) == (target_prob == nullptr)) return VMC_E_ARG;       // exactly one kind of target
+  if (workspace_bytes < vmc_loss_workspace_bytes(rows)) return VMC_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, target_index, target_prob, (float*)workspace, dlogits, rows, C);
+  VMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, loss, rows, 1.0f / (float)rows);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- fused Adam / AdamW ---------------------------------------------------------------------------
 // 16 B read (p, g, m, v) + 12 B write per parameter; float4 vectorised, grid-stride.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -82,6 +82,43 @@ def bce_with_logits_loss(predictions, targets):
     return _BceFn.apply(predictions, targets, -1.0)
 
 
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.contiguous().float()
+        if x.dim() != 2:
+            raise ValueError(f"cross_entropy_loss expects [rows, classes] logits, got {tuple(x.shape)}")
+        rows, C = x.shape
+        if target.is_floating_point():
+            if target.shape != x.shape:
+                raise ValueError(f"probability targets must have the logits' shape {tuple(x.shape)}, got {tuple(target.shape)}")
+            tidx, tprob = None, target.contiguous().float()
+        else:
+            if target.shape != (rows,):
+                raise ValueError(f"index targets must have shape ({rows},), got {tuple(target.shape)}")
+            tidx, tprob = target.contiguous().to(torch.int64), None
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if logits.requires_grad else None
+        ws = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.vmc_cross_entropy_loss(ptr(x), ptr(tidx), ptr(tprob), ptr(loss), ptr(dx), rows, C, ptr(ws), rows * 4, stream()),
+              "cross_entropy_loss")
+        ctx.save_for_backward(dx)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return ag.scale_by_device_scalar(dx, g).view(ctx.shape), None
+
+
+def cross_entropy_loss(predictions, targets):
+    """nn.CrossEntropyLoss() (mean) as used by the MammalNet variants: class-index targets
+    (train_frame_diff_mn.py:102 ``labels.argmax(dim=1)``) or float probability rows
+    (TFAM/train_and_eval_frame_diff_MN.py:83 passes the one-hot ``labels`` directly)."""
+    return _CrossEntropyFn.apply(predictions, targets)
+
+
 def reconstruction_loss(reconstruction, input):  # noqa: A002  (reference signature)
     """losses.py:70-81."""
     raise NotImplementedError

@@ -46,6 +46,43 @@ class MultilabelAveragePrecision:
     __call__ = update
 
 
+class Accuracy:
+    """Top-1 accuracy for the single-label MammalNet variants (TFAM/train_and_eval_frame_diff_MN.py:49,87,94:
+    ``Accuracy(num_classes=C)``; ``update(logits [N,C], labels.int() [N,C])``).  The reference hands the metric one-hot
+    integer rows; torchmetrics is not installed here and its legacy ``Accuracy(num_classes=...)`` call form no longer
+    exists in the version SURVEY.md pins (1.7.1 requires ``task=``), so the intended statistic — fraction of rows whose
+    arg-max logit is the labelled class — is what is computed ("parity unpinned")."""
+
+    def __init__(self, num_classes: int, **unused):
+        self.num_classes = num_classes
+        self.reset()
+
+    def to(self, device):
+        return self
+
+    def reset(self):
+        self._correct = self._total = None
+
+    def update(self, preds: torch.Tensor, target: torch.Tensor):
+        p = preds.detach().reshape(-1, self.num_classes).argmax(dim=1)
+        t = target.detach()
+        t = t.reshape(-1, self.num_classes).argmax(dim=1) if t.dim() >= 2 or t.numel() != p.numel() else t.reshape(-1).to(torch.int64)
+        c = (p == t).sum().to(torch.float64).reshape(1)
+        n = torch.tensor([float(p.numel())], dtype=torch.float64, device=c.device)
+        self._correct = c if self._correct is None else self._correct + c
+        self._total = n if self._total is None else self._total + n
+
+    def compute(self, distributed: bool = False) -> torch.Tensor:
+        if self._total is None:
+            return torch.tensor(float("nan"))
+        c, n = self._correct, self._total
+        if distributed:
+            c, n = parallel.all_gather_rows(c.reshape(1, 1)).sum().reshape(1), parallel.all_gather_rows(n.reshape(1, 1)).sum().reshape(1)
+        return (c / n).to(torch.float32).reshape(())
+
+    __call__ = update
+
+
 def micro_average_precision(scores: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
     """scores in [0,1] [N,C], targets {0,1} [N,C] -> scalar AP (float64 accumulation)."""
     s = scores.reshape(-1)

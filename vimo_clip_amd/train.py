@@ -1,6 +1,10 @@
 """MoCLIP student training loop on the MI355X engine — the hot loop of the reference's train.py (train :52-175,
 evaluate :14-49) with the same argument names, one process per GPU under torchrun instead of nn.DataParallel (:64).
-Real data needs h5py + a video decoder (absent offline): ``--synthetic N`` trains on N synthetic segments instead.
+``--clip_embeddings_dir`` / ``--flow_videos_dir`` read the reference's HDF5 + video layout (HDF5 natively through
+h5lite; decoded ``.npy`` frame stacks when no video decoder is installed); ``--synthetic N`` trains on N synthetic
+segments.  ``--single_label`` is the MammalNet variant (train_frame_diff_mn.py:82,102: CrossEntropy on
+``labels.argmax(dim=1)``, no gradient clipping); ``--motion_key frame_diff`` the frame-difference twin
+(train_frame_diff.py: batch key ``frame_diff`` instead of ``flow_frames``).
 """
 from __future__ import annotations
 
@@ -12,7 +16,7 @@ import torch
 
 from . import parallel
 from .dataset import SyntheticSegmentDataset, collate_fn
-from .losses import classification_loss, distillation_loss
+from .losses import classification_loss, cross_entropy_loss, distillation_loss
 from .models.student_model import FlowStudentModel
 from .optim import FusedAdam, GradArena
 
@@ -23,14 +27,24 @@ def _batches(ds, batch_size, rank, world):
         yield collate_fn([ds[i] for i in range(s, s + batch_size)])
 
 
-def evaluate(model, val_set, device, distillation_loss_mode, class_positive_weight, batch_size, rank=0, world=1):
+def _frames(batch):
+    return batch["flow_frames"] if "flow_frames" in batch else batch["frame_diff"]
+
+
+def _class_loss(logits, labels, class_positive_weight, single_label):
+    if single_label:                                   # train_frame_diff_mn.py:102
+        return cross_entropy_loss(logits, labels.argmax(dim=1))
+    return classification_loss(logits, labels, positive_weight=class_positive_weight)
+
+
+def evaluate(model, val_set, device, distillation_loss_mode, class_positive_weight, batch_size, rank=0, world=1, single_label=False):
     model.eval()
     tot = torch.zeros(4, device=device)
     with torch.no_grad():
         for batch in _batches(val_set, batch_size, rank, world):
-            _, emb_d, logits = model(batch["flow_frames"].to(device))
+            _, emb_d, logits = model(_frames(batch).to(device))
             dl = distillation_loss(emb_d, batch["rgb_emb"].to(device)[:, :-1, :], mode=distillation_loss_mode)
-            cl = classification_loss(logits, batch["labels"].to(device), positive_weight=class_positive_weight)
+            cl = _class_loss(logits, batch["labels"].to(device), class_positive_weight, single_label)
             tot += torch.stack([dl, cl, dl + cl, torch.ones((), device=device)])
     tot = parallel.all_reduce_scalars(tot)
     n = max(1.0, float(tot[3]))
@@ -41,8 +55,15 @@ def train(args):
     rank, world, local = parallel.init_from_env()
     device = f"cuda:{local}"
     E = {"ViT-B/32": 512, "ViT-B/16": 512, "ViT-L/14": 768}.get(args.clip_model_name, 512)
-    train_set = SyntheticSegmentDataset(args.synthetic, args.sequence_length, E, args.num_classes, seed=3)
-    val_set = SyntheticSegmentDataset(max(args.batch_size * world, args.synthetic // 8), args.sequence_length, E, args.num_classes, seed=4)
+    single = bool(getattr(args, "single_label", False))
+    if getattr(args, "clip_embeddings_dir", None):
+        from .dataset import HDF5VideoDataset
+        train_set = HDF5VideoDataset(args.clip_embeddings_dir, args.flow_videos_dir, sequence_length=args.sequence_length)
+        val_set = HDF5VideoDataset(args.val_clip_embeddings_dir or args.clip_embeddings_dir, args.val_flow_videos_dir or args.flow_videos_dir,
+                                   sequence_length=args.sequence_length)
+    else:
+        train_set = SyntheticSegmentDataset(args.synthetic, args.sequence_length, E, args.num_classes, seed=3)
+        val_set = SyntheticSegmentDataset(max(args.batch_size * world, args.synthetic // 8), args.sequence_length, E, args.num_classes, seed=4)
     model = FlowStudentModel(clip_model_name=args.clip_model_name, device=device, num_classes=args.num_classes, alpha=args.residual_alpha)
     arena = GradArena(model.parameters())
     parallel.broadcast_parameters(arena.flat_param)
@@ -53,14 +74,15 @@ def train(args):
         model.train()
         t0, nframes = time.time(), 0
         for batch in _batches(train_set, args.batch_size, rank, world):
-            emb, emb_d, logits = model(batch["flow_frames"].to(device))
+            frames = _frames(batch)
+            emb, emb_d, logits = model(frames.to(device))
             dl = distillation_loss(emb_d, batch["rgb_emb"].to(device)[:, :-1, :], mode=args.distillation_loss_mode)
-            cl = classification_loss(logits, batch["labels"].to(device), positive_weight=args.class_positive_weight)
+            cl = _class_loss(logits, batch["labels"].to(device), args.class_positive_weight, single)
             (dl + cl).backward()
-            optimizer.step(grad_scale=reducer.all_reduce(), max_grad_norm=args.grad_clip_norm)
-            nframes += batch["flow_frames"].shape[0] * batch["flow_frames"].shape[1]
+            optimizer.step(grad_scale=reducer.all_reduce(), max_grad_norm=None if single else args.grad_clip_norm)
+            nframes += frames.shape[0] * frames.shape[1]
         torch.cuda.synchronize()
-        vd, vc, vt = evaluate(model, val_set, device, args.distillation_loss_mode, args.class_positive_weight, args.batch_size, rank, world)
+        vd, vc, vt = evaluate(model, val_set, device, args.distillation_loss_mode, args.class_positive_weight, args.batch_size, rank, world, single)
         best = min(best, vt)
         if rank == 0:
             print(json.dumps({"epoch": epoch + 1, "val_distill": vd, "val_class": vc, "val_total": vt,
@@ -81,4 +103,9 @@ if __name__ == "__main__":
     p.add_argument("--class_positive_weight", type=int, default=9)
     p.add_argument("--residual_alpha", type=float, default=0.1)
     p.add_argument("--grad_clip_norm", type=float, default=None)
+    p.add_argument("--single_label", action="store_true", help="MammalNet variant: CrossEntropy on labels.argmax(1)")
+    p.add_argument("--clip_embeddings_dir", default=None, help="HDF5 file of teacher embeddings (reference layout)")
+    p.add_argument("--flow_videos_dir", default=None)
+    p.add_argument("--val_clip_embeddings_dir", default=None)
+    p.add_argument("--val_flow_videos_dir", default=None)
     train(p.parse_args())
