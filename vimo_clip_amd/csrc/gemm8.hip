@@ -205,6 +205,39 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
 
   const bool vec8 = gemm_vec8_ok(g);
+  // Interior tile writing 16-bit rows without residual / row remap (qkv, c_fc, dgrad): branch-free epilogue, the bias of
+  // this lane's 2 x 8 columns loaded once instead of once per row (the generic path below cannot hoist it past the stores).
+  if (vec8 && !g.out_f32 && !g.res && !g.out_row_group && m0 + 256 <= g.M && n0 + 256 <= g.N) {
+    float bv[2][8];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int col = n0 + 128 * nh + 32 * wn + 8 * q;
+      if (g.bias) {
+        const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
+        bv[nh][0] = b0.x; bv[nh][1] = b0.y; bv[nh][2] = b0.z; bv[nh][3] = b0.w;
+        bv[nh][4] = b1.x; bv[nh][5] = b1.y; bv[nh][6] = b1.z; bv[nh][7] = b1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[nh][j] = 0.f;
+      }
+    }
+    uint16_t* cbase = (uint16_t*)g.C + (size_t)(m0 + 64 * wm + r) * g.ldc + n0 + 32 * wn + 8 * q;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          float v[8];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * nt + j] = g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][j] + bv[nh][4 * nt + j]);
+          *(uint4*)(cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh) =
+              make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+        }
+    return;
+  }
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
