@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the TFAM measurements")
+    ap.add_argument("--no-fuse-add-ln", action="store_true", help="A/B: residual add in the GEMM epilogue + plain LayerNorm")
     ap.add_argument("--chunk", type=int, default=0, help="frames per encoder pass inside a step (0 = all frames of the step at once)")
     args = ap.parse_args()
 
@@ -168,6 +169,8 @@ def main():
     sd = synth.vit_state_dict(args.model, seed=2)
     model.load_state_dict(sd, strict=True)
     model.frame_chunk = args.chunk or args.frames
+    if args.no_fuse_add_ln:
+        model.fuse_add_ln = False
     R = model.input_resolution
     frames = synth.randint_u8(1 + rank, "frames", (args.frames, 3, R, R)).to(dev)   # random, never zeros (DVFS)
 

@@ -92,6 +92,7 @@ class VisionTransformer(nn.Module):
         self.compute_dtype = compute_dtype
         self.residual_dtype = residual_dtype
         self._w16 = {}          # name -> (param version, 16-bit copy)
+        self.fuse_add_ln = True  # False: x += GEMM in the epilogue (fp32 read-modify-write), plain LayerNorm after it
         self.frame_chunk = 256  # frames per pass (bounds activation memory; F*N*4D*2 B for the MLP buffer)
         self._init_weights()
 
@@ -138,7 +139,7 @@ class VisionTransformer(nn.Module):
             ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias, dt16, out16=False, out32=True, y32=x)
         else:
             self._ln_inplace16(x, self.ln_pre)
-        fused = xf32 and D % 256 == 0          # residual add fused into the next LayerNorm (vmc_add_layernorm_fwd)
+        fused = xf32 and D % 256 == 0 and self.fuse_add_ln   # residual add fused into the next LayerNorm (vmc_add_layernorm_fwd)
         blocks = list(self.transformer.resblocks)
         h = None
         for i, blk in enumerate(blocks):

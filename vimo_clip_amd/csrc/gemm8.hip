@@ -238,6 +238,55 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
         }
     return;
   }
+  // Interior tile accumulating into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of
+  // four tile rows are fetched together (8 x 32 B per lane in flight), then added and stored; no per-row branches.
+  if (vec8 && g.out_f32 && g.res && g.res_f32 && !g.out_row_group && !g.res_row_mod && m0 + 256 <= g.M && n0 + 256 <= g.N) {
+    float bv[2][8];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int col = n0 + 128 * nh + 32 * wn + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[nh][j] = 0.f;
+      if (g.bias) {
+        const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
+        bv[nh][0] = b0.x; bv[nh][1] = b0.y; bv[nh][2] = b0.z; bv[nh][3] = b0.w;
+        bv[nh][4] = b1.x; bv[nh][5] = b1.y; bv[nh][6] = b1.z; bv[nh][7] = b1.w;
+      }
+    }
+    const size_t roff = (size_t)(m0 + 64 * wm + r);
+    const int coff = n0 + 32 * wn + 8 * q;
+    const float* rbase = (const float*)g.res + roff * g.ldres + coff;
+    float* cbase = (float*)g.C + roff * g.ldc + coff;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      float4 rr[4][2][2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const float* src = rbase + (size_t)(128 * mh + 16 * mt) * g.ldres + 128 * nh;
+          rr[mt][nh][0] = *(const float4*)src;
+          rr[mt][nh][1] = *(const float4*)(src + 4);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          float* dst = cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float4 x = rr[mt][nh][nt];
+            float4 o;
+            o.x = x.x + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][0] + bv[nh][4 * nt + 0]);
+            o.y = x.y + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][1] + bv[nh][4 * nt + 1]);
+            o.z = x.z + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][2] + bv[nh][4 * nt + 2]);
+            o.w = x.w + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][3] + bv[nh][4 * nt + 3]);
+            *(float4*)(dst + 4 * nt) = o;
+          }
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
