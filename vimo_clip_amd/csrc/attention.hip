@@ -13,30 +13,45 @@
 // ==================================================================================================
 // One chunk of NKS 32-key steps starting at step KS0 for a 16-query tile: S^T = K Q^T, running max update,
 // rescale of the accumulators, P = exp2(c2 s - c2 m) packed to 16 bits, O^T += V^T P^T, rowsum += 1^T P^T.
-template <typename T, int KS0, int NKS>
+// attention.hip is compiled with -fno-honor-nans (Makefile): fmaxf then lowers to bare v_max_f32 / v_max3_f32 instead of
+// quieting each operand first (v_max_f32 x, x); scores are finite or -inf, never NaN.
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// NC > 0: the key count is the compile-time constant NC (the three CLIP geometries: 50 / 197 / 257 tokens), so the
+// padded-key masks fold to constants -- only the one tile that straddles NC executes compares, tiles past it skip their
+// MFMAs.  NC == 0: runtime N (every tile carries a wave-uniform test, which hipcc lowers to two v_cndmask per score).
+template <typename T, int KS0, int NKS, int NC>
 __device__ __forceinline__ void attn_chunk(const char* k_lds, const char* v_lds, int koff0, int koff1, const int (&voff)[4],
-                                           const uint4 (&qf)[2], int N, int q, float c2, float& m, f32x4 (&o)[4], f32x4& osum) {
+                                           const uint4 (&qf)[2], int Nrt, int q, float c2, float& m, f32x4 (&o)[4], f32x4& osum) {
   constexpr int NTC = 2 * NKS, NT0 = 2 * KS0;
+  const int N = NC > 0 ? NC : Nrt;
   f32x4 s[NTC];
 #pragma unroll
   for (int t = 0; t < NTC; ++t) {
+    if (NC > 0 && 16 * (NT0 + t) >= NC) {      // tile of padded keys only
+      s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      continue;
+    }
     s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     s[t] = T::mfma16(*(const uint4*)(k_lds + koff0 + (NT0 + t) * 2048), qf[0], s[t]);
     s[t] = T::mfma16(*(const uint4*)(k_lds + koff1 + (NT0 + t) * 2048), qf[1], s[t]);
   }
 #pragma unroll
   for (int t = 0; t < NTC; ++t)
-    if (16 * (NT0 + t) + 16 > N) {  // wave-uniform: only tiles that can hold padded keys are masked
+    if (16 * (NT0 + t) + 16 > N && !(NC > 0 && 16 * (NT0 + t) >= NC)) {  // only the tile that straddles N is masked
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (16 * (NT0 + t) + 4 * q + j >= N) s[t][j] = -INFINITY;
     }
-  float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+  float mx = vmax3(s[0][0], s[0][1], vmax3(s[0][2], s[0][3], -INFINITY));
 #pragma unroll
-  for (int t = 1; t < NTC; ++t) mx = fmaxf(fmaxf(fmaxf(mx, s[t][0]), fmaxf(s[t][1], s[t][2])), s[t][3]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float mnew = fmaxf(m, mx);          // key 0 is always valid, so mnew is finite from the first chunk on
+  for (int t = 1; t < NTC; ++t) {
+    if (NC > 0 && 16 * (NT0 + t) >= NC) continue;
+    mx = vmax3(vmax3(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
+  }
+  mx = vmax3(mx, __shfl_xor(mx, 16, 64), -INFINITY);
+  mx = vmax3(mx, __shfl_xor(mx, 32, 64), -INFINITY);
+  const float mnew = vmax3(m, mx, -INFINITY);   // key 0 is always valid, so mnew is finite from the first chunk on
   if (KS0 > 0) {                            // rescale what the earlier chunk accumulated (exp2(-inf) never occurs here)
     const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
 #pragma unroll
@@ -89,7 +104,7 @@ __device__ __forceinline__ void attn_chunk(const char* k_lds, const char* v_lds,
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int NC>
 __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,8 +174,8 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
     float m = -INFINITY;
     constexpr int KS = NT / 2;                         // 32-key steps
     constexpr int KA = NT >= 14 ? (KS + 1) / 2 : KS;   // steps in the first chunk
-    attn_chunk<T, 0, KA>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
-    if constexpr (KS > KA) attn_chunk<T, KA, KS - KA>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
+    attn_chunk<T, 0, KA, NC>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
+    if constexpr (KS > KA) attn_chunk<T, KA, KS - KA, NC>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
     const float sum = osum[0];   // every accumulator row holds the full row sum of query r (16-bit rounded P, as P V uses)
     const float inv = 1.0f / sum;
     if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
@@ -173,9 +188,9 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   }
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int NC = 0>
 static int launch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t stream) {
-  auto kern = attn_vit_kernel<T, NT>;
+  auto kern = attn_vit_kernel<T, NT, NC>;
   constexpr int LDS = 16 * NT * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -190,6 +205,9 @@ static int launch_vit(const void* qkv, void* out, float* lse, int F, int N, int 
 
 template <typename T>
 static int dispatch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t s) {
+  if (N == 257) return launch_vit<T, 18, 257>(qkv, out, lse, F, N, H, s);   // ViT-L/14 @ 224
+  if (N == 197) return launch_vit<T, 14, 197>(qkv, out, lse, F, N, H, s);   // ViT-B/16
+  if (N == 50) return launch_vit<T, 4, 50>(qkv, out, lse, F, N, H, s);      // ViT-B/32
   if (N <= 32) return launch_vit<T, 2>(qkv, out, lse, F, N, H, s);
   if (N <= 64) return launch_vit<T, 4>(qkv, out, lse, F, N, H, s);
   if (N <= 128) return launch_vit<T, 8>(qkv, out, lse, F, N, H, s);

@@ -57,7 +57,20 @@ __device__ __forceinline__ void gemm_step(const char* __restrict__ rd, char* __r
   }
 }
 
-template <typename T, int ACT, int MT, int WM, int WN>
+// inline-asm fragment read for the ring variant (same reason as gemm8.hip: no compiler-inserted vmcnt(0) while DMAs fly)
+template <int IMM>
+__device__ __forceinline__ void ring_read128(uint4& v, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS == 2: the two-stage loop above.  NS > 2: an NS-stage LDS ring with NS-1 K tiles in flight and counted vmcnt --
+// for the latency-bound small problems (few workgroups per CU, e.g. the 256-row tail of a large GEMM), where one
+// exposed L2/HBM round trip per K tile is the whole run time.
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2>
 __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   using Cfg = GemmCfg<MT, WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,6 +129,51 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   for (int i = 0; i < Cfg::A_ITERS; ++i) a_src[i] += (size_t)kt0 * 128;
 #pragma unroll
   for (int i = 0; i < Cfg::B_ITERS; ++i) b_src[i] += (size_t)kt0 * 128;
+  if constexpr (NS > 2) {
+    constexpr int LOADS = Cfg::A_ITERS + Cfg::B_ITERS;      // LDS-DMA instructions per thread per stage
+    static_assert(LOADS * (NS - 2) <= 63, "vmcnt field");
+    auto stage_in = [&](int t) {
+      char* dst = smem + (t % NS) * Cfg::STAGE;
+      const size_t koff = (size_t)t * 128;
+#pragma unroll
+      for (int i = 0; i < Cfg::A_ITERS; ++i)
+        __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(a_src[i] + koff), (VMC_LDS void*)(dst + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < Cfg::B_ITERS; ++i)
+        __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(b_src[i] + koff),
+                                         (VMC_LDS void*)(dst + Cfg::A_BYTES + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < nkt) stage_in(t);
+    for (int kt = 0; kt < nkt; ++kt) {
+      // stage kt must have landed; up to NS-2 younger stages may stay in flight
+      const int younger = min(NS - 2, nkt - 1 - kt);
+      if (younger >= NS - 2) ring_wait_vm<LOADS * (NS - 2)>();
+      else if (NS > 3 && younger == NS - 3) ring_wait_vm<LOADS * (NS - 3 > 0 ? NS - 3 : 0)>();
+      else if (NS > 4 && younger == NS - 4) ring_wait_vm<LOADS * (NS - 4 > 0 ? NS - 4 : 0)>();
+      else ring_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();            // every wave sees stage kt and is done reading stage kt-1 ...
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NS - 1 < nkt) stage_in(kt + NS - 1);   // ... whose ring slot the new DMA overwrites
+      const uint32_t base = (uint32_t)(uintptr_t)(const VMC_LDS char*)(smem + (kt % NS) * Cfg::STAGE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 wf[4], xf[MT];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ring_read128<0>(wf[nt], base + (uint32_t)woff[kk][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ring_read128<0>(xf[mt], base + (uint32_t)(xoff[kk] + mt * 2048));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = T::mfma16(wf[nt], xf[mt], acc[mt][nt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   char* const buf0 = smem;
   char* const buf1 = smem + Cfg::STAGE;
   // prologue: tile 0 -> buf0
@@ -140,6 +198,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
     __syncthreads();
     gemm_step<T, MT, WM, WN>(buf0, buf1, false, 0, a_src, b_src, wave_lds, xoff, woff, acc);
   }
+  }  // NS == 2
 
   // ---- epilogue: lane owns C[row][col0 .. col0+15] for each mt ----
   const int col0 = n0 + wn * 64 + 16 * q;
@@ -213,19 +272,20 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   }
 }
 
-template <typename T, int ACT, int MT, int WM, int WN>
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2>
 static int launch_cfg(GemmArgs& g, hipStream_t stream) {
   using Cfg = GemmCfg<MT, WM, WN>;
-  auto kern = gemm_kernel<T, ACT, MT, WM, WN>;
+  auto kern = gemm_kernel<T, ACT, MT, WM, WN, NS>;
+  constexpr int LDS = NS * Cfg::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
   g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.k_slices), dim3(Cfg::NT), Cfg::LDS, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.k_slices), dim3(Cfg::NT), LDS, stream, g);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -238,7 +298,7 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
   if (t256 >= 192) return launch_cfg<T, ACT, 8, 2, 4>(g, stream);
   if (t128 >= 128) return launch_cfg<T, ACT, 4, 2, 2>(g, stream);
-  return launch_cfg<T, ACT, 2, 2, 1>(g, stream);
+  return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);      // 64x64 tiles: latency-bound -> 4-stage ring
 }
 
 template <typename T>
