@@ -156,9 +156,12 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) voff[dt] = lds_off_v(4 * q + (r >> 2), 2 * dt + ((r & 3) >> 1)) + (r & 1) * 8;
   uint4 qnext[2];
+  // nqt = 17 for N = 257: one wave owns five query tiles, the others four.  Waves w of co-resident workgroups share a
+  // SIMD, so the long wave rotates with the block index instead of always landing on SIMD 0.
+  const int w0 = (wave + blockIdx.x) & 3;
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(wave * 16 + r, N - 1) * ld + (4 * kk + q) * 8);
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(w0 * 16 + r, N - 1) * ld + (4 * kk + q) * 8);
+  for (int qt = w0; qt < nqt; qt += 4) {
     const int qrow = qt * 16 + r;
     uint4 qf[2] = {qnext[0], qnext[1]};
     if (qt + 4 < nqt) {  // prefetch the next query tile's fragments under this tile's MFMAs
