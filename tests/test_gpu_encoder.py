@@ -97,3 +97,29 @@ def test_encoder_on_non_square_frames_vs_oracle():
     ref = ovit.vit_forward(sd, ovit.normalize_u8(pre), 12)
     y = m.encode_frames_u8(u8.cuda(), wrap_quirk=True).cpu()
     assert (y - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_full_size_workload_properties_vit_l14():
+    """BASELINE.json configs[1] at full size (ViT-L/14, B*T = 256 frames = 65 792 token rows: the bench workload), checked
+    through size-independent properties since the CPU oracle needs minutes for it: (a) frames are independent -- one pass
+    over 256 frames, four passes over 64 and a shuffled pass give the same bits per frame although the GEMMs then take
+    different kernels (8-phase tiles + 256-row tail vs other tile counts); (b) a 3-frame sample of the same batch agrees
+    with the CPU oracle within the bf16 tolerance."""
+    name, seed = "ViT-L/14", 2
+    from vimo_clip_amd.clip_vit import VisionTransformer
+    m = VisionTransformer.from_name(name, compute_dtype=torch.bfloat16).to("cuda").eval()
+    sd = synth.vit_state_dict(name, seed)
+    m.load_state_dict(sd, strict=True)
+    u8 = synth.randint_u8(1, "frames", (256, 3, 224, 224)).cuda()
+    m.frame_chunk = 256
+    full = m.encode_frames_u8(u8)
+    assert full.shape == (256, 768) and torch.isfinite(full).all()
+    m.frame_chunk = 64
+    assert torch.equal(m.encode_frames_u8(u8), full)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).cuda()
+    m.frame_chunk = 256
+    assert torch.equal(m.encode_frames_u8(u8[perm]), full[perm])
+    pick = [0, 131, 255]
+    ref = ovit.vit_forward(sd, ovit.normalize_u8(u8[pick].cpu()), 16)
+    err = (full[pick].cpu() - ref).abs().max().item()
+    assert err <= TOL[torch.bfloat16] * max(1.0, ref.abs().max().item()), err

@@ -272,3 +272,31 @@ def test_tfam_single_label_training_learns():
                  epochs=3, batch_size=16, dropout=0.0, mlp_dropout=0.0, device="cuda:0", mode="both")
     res = run(cfg, limit=512)
     assert res["task"] == "singlelabel" and res["best_val_metric"] > 0.5 and res["test_metric"] > 0.5, res
+
+
+def test_full_size_tfam_batch_properties():
+    """BASELINE.json TFAM configuration at full size (D = 768, 4 layers, 16 + 15 tokens, B = 4096 clips, ragged masks):
+    clips are independent -- a 4096-clip pass, its 512-clip slices and a shuffled pass give the same logits bit for bit --
+    and a 4-clip sample agrees with the CPU oracle within the bf16 tolerance."""
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    D, H, L, FF, C, seed, B = 768, 8, 4, 2048, 140, 4, 4096
+    m = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda().eval()
+    sd = synth.tfam_state_dict(D, H, L, FF, C, seed)
+    m.load_state_dict(sd, strict=True)
+    rgb, mot = synth.normal(71, "rgb", (B, 16, D)), synth.normal(71, "mot", (B, 15, D))
+    lr, lf = synth.randint(71, "lr", (B,), 3, 17), synth.randint(71, "lf", (B,), 2, 16)
+    mr, mf = torch.arange(16)[None] < lr[:, None], torch.arange(15)[None] < lf[:, None]
+    d = lambda *t: [x.cuda() for x in t]
+    with torch.no_grad():
+        R, M, MR, MF = d(rgb, mot, mr, mf)
+        full = m(R, M, mask_rgb=MR, mask_flow=MF)
+        assert full.shape == (B, C) and torch.isfinite(full).all()
+        for s in (0, 1536, 3584):
+            part = m(R[s:s + 512], M[s:s + 512], mask_rgb=MR[s:s + 512], mask_flow=MF[s:s + 512])
+            assert torch.equal(part, full[s:s + 512])
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+        assert torch.equal(m(R[perm], M[perm], mask_rgb=MR[perm], mask_flow=MF[perm]), full[perm])
+    pick = [0, 1000, 2047, 4095]
+    ref = otfam.amo_clip_forward(sd, rgb[pick], mot[pick], mr[pick], mf[pick], nhead=H)
+    err = (full[pick].cpu() - ref).abs().max().item()
+    assert err <= TOL[torch.bfloat16] * max(1.0, ref.abs().max().item()), err
