@@ -92,7 +92,7 @@ def tfam_extras(dev, rank, world, cdt):
     arena = GradArena(m.used_parameters())
     broadcast_parameters(arena.flat_param)
     opt = FusedAdam(arena, lr=1e-4, weight_decay=0.1, decoupled=True)
-    red = GradientAllReducer(arena.flat_grad)
+    red = GradientAllReducer(arena.flat_grad).attach(arena)      # bucket all-reduces overlap the backward (N > 1)
     rgb = synth.normal(20 + rank, "rgb_t", (B, 16, 768)).to(dev)
     mot = synth.normal(20 + rank, "mot_t", (B, 16, 768)).to(dev)
     mk = torch.ones(B, 16, dtype=torch.bool, device=dev)

@@ -158,3 +158,61 @@ def test_streaming_student_export_matches_oracle(tmp_path):
         assert d.shape == (13, 512) and d.chunks == (5, 512) and d.maxshape == (None, 512)
         got = torch.from_numpy(d[:])
     assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vimo_clip_amd import autograd_ops, parallel
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    dist.init_process_group("gloo")                        # two ranks share the one GPU of the box: gloo instead of RCCL
+    try:
+        out = []
+        for overlap in (False, True):
+            autograd_ops.grad_ready_hooks.clear()
+            m = AMO_CLIP(d_model=256, nhead=4, num_layers=2, dim_feedforward=512, num_classes=24, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda().train()
+            m.load_state_dict(synth.tfam_state_dict(256, 4, 2, 512, 24, 9), strict=True)
+            arena = GradArena(m.used_parameters())
+            opt = FusedAdam(arena, lr=1e-3, weight_decay=0.1, decoupled=True)
+            red = parallel.GradientAllReducer(arena.flat_grad, bucket_bytes=256 * 1024)
+            if overlap:
+                red.attach(arena)
+            early = []
+            for step in range(3):
+                rgb = synth.normal(100 * rank + step, "r", (16, 12, 256)).cuda()
+                mot = synth.normal(100 * rank + step, "m", (16, 11, 256)).cuda()
+                y = synth.multi_hot_labels(100 * rank + step, "y", 16, 24).cuda()
+                bce_with_logits_loss(m(rgb, mot), y).backward()
+                opt.step(grad_scale=red.all_reduce())
+                early.append(red.overlapped_last_step)
+            out.append((arena.flat_param.detach().cpu().clone(), early, len(red.buckets)))
+        (p0, _, _), (p1, early, nb) = out
+        q.put((rank, bool(torch.equal(p0, p1)), early, nb, float(p0.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_backward_overlapped_allreduce_two_ranks_one_gpu():
+    """bucket all-reduces issued during the backward give exactly the parameters of the reduce-after-backward
+    schedule; two ranks (different data) on the one GPU of the box, gloo transport."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res                       # overlapped == not overlapped, bit for bit
+    assert res[0][4] == res[1][4]                            # replicas stay identical
+    early, nb = res[0][2], res[0][3]
+    assert early[0] == 0 and early[1] >= nb - 1 and early[2] >= nb - 1, (early, nb)

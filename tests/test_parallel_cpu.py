@@ -33,6 +33,38 @@ def _worker(rank, world, port, q):
         want[0::7] += 0.5
         want[1::7] += 0.5
         assert scale == 0.5 and torch.equal(flat, want)
+        # ---- bucket launches overlapped with the backward (attach): reports arrive in reverse parameter order ----
+        class _P:                                            # stand-in for a parameter: only numel() and identity matter
+            def __init__(self, n):
+                self.n = n
+
+            def numel(self):
+                return self.n
+
+        class _Arena:
+            pass
+        sizes = [300, 5000, 64, 9000, 128, 4096, 700]        # 64-aligned offsets; several parameters straddle 4096-element buckets
+        ar = _Arena()
+        ar.params = [_P(nn) for nn in sizes]
+        ar.offsets, off = [], 0
+        for nn in sizes:
+            ar.offsets.append(off)
+            off += (nn + 63) // 64 * 64
+        g = torch.zeros(off)
+        red2 = parallel.GradientAllReducer(g, bucket_bytes=4096 * 4).attach(ar, register=False)
+        unused = {2}                                         # a parameter the fusion mode never touches
+        twice = {3}                                          # a packed in_proj: two row-slice reports per backward
+        for step in range(3):
+            g.fill_(float(rank + 1) * (step + 1))
+            for i in reversed(range(len(sizes))):
+                if i in unused:
+                    continue
+                for _ in range(2 if i in twice else 1):
+                    red2.on_grad_ready(ar.params[i])
+            scale2 = red2.all_reduce()
+            assert scale2 == 0.5 and torch.all(g == 3.0 * (step + 1)), (step, g.unique())
+            early = red2.overlapped_last_step
+            assert (early == 0) if step == 0 else (early >= len(red2.buckets) - 2), (step, early, len(red2.buckets))
         p = torch.full((10,), float(rank))
         parallel.broadcast_parameters(p, src=0)
         assert torch.all(p == 0)

@@ -104,7 +104,7 @@ class ModelTrainer:
         parallel.broadcast_parameters(self.arena.flat_param)
         self.optimizer = FusedAdam(self.arena, lr=1e-4, weight_decay=0.1, decoupled=True)       # lr hard-coded as :53
         self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.epochs, eta_min=1e-6)
-        self.reducer = parallel.GradientAllReducer(self.arena.flat_grad)
+        self.reducer = parallel.GradientAllReducer(self.arena.flat_grad).attach(self.arena)   # buckets go out during the backward
 
     def _forward(self, batch):
         return _model_forward(self.model, batch, self.config), batch["labels"].to(self.config.device)

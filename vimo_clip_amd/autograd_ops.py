@@ -52,6 +52,9 @@ def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+grad_ready_hooks = []      # callables(param): a backward kernel has just written (part of) this parameter's arena gradient
+
+
 def _deliver(param, grad):
     """Write a parameter gradient into its arena slot (if any) and tell autograd nothing is left to do."""
     if param is None or not param.requires_grad:
@@ -61,6 +64,8 @@ def _deliver(param, grad):
         return grad.view(param.shape) if grad.shape != param.shape else grad
     if grad.data_ptr() != slot.data_ptr():
         slot.view(-1).copy_(grad.reshape(-1))      # device-to-device copy (plumbing); GEMMs write in place below
+    for hook in grad_ready_hooks:                  # data-parallel reducer: launch a bucket as soon as it is complete
+        hook(param)
     return None
 
 

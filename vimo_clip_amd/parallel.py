@@ -48,29 +48,104 @@ def shard_range(n_items: int, rank: int, world: int, drop_last: bool = True):
 
 
 class GradientAllReducer:
-    """Bucketed asynchronous SUM all-reduce of a flat gradient buffer."""
+    """Bucketed asynchronous SUM all-reduce of a flat gradient buffer.
+
+    Plain use: ``all_reduce()`` after the backward issues every bucket and waits.  With ``attach(arena)`` the buckets are
+    issued *during* the backward: backward kernels write gradients straight into the arena and report each
+    parameter (``autograd_ops.grad_ready_hooks``); a bucket goes out on the RCCL stream the moment the last parameter that
+    overlaps it is complete, i.e. in reverse layer order while earlier layers are still back-propagating.  How many reports
+    a parameter gets per backward (a packed ``in_proj`` is written in two row slices) is learned from the first step, which
+    runs un-overlapped; parameters that never report (unused in the fusion mode) are flushed by ``all_reduce()``.  Every rank
+    runs the same graph, so the launch order of the collectives is the same on every rank."""
 
     def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 48 << 20):
         self.flat = flat_grad
         n = max(64, bucket_bytes // flat_grad.element_size())
+        self.bucket_elems = n
         self.buckets = [flat_grad[s:min(flat_grad.numel(), s + n)] for s in range(0, flat_grad.numel(), n)]
         self._pending = []
+        self._attached = False
 
+    # ---- overlap with the backward ------------------------------------------------------------------
+    def attach(self, arena, register: bool = True):
+        """arena: optim.GradArena (``params`` + ``offsets`` into the flat gradient buffer)."""
+        self._pbuckets = {}
+        for p, o in zip(arena.params, arena.offsets):
+            b0, b1 = o // self.bucket_elems, (o + max(1, p.numel()) - 1) // self.bucket_elems
+            self._pbuckets[id(p)] = list(range(b0, b1 + 1))
+        self._expected = None                      # id(param) -> reports per backward, learned in the first step
+        self._counts = {}
+        self._launched = [False] * len(self.buckets)
+        self._remaining = None
+        self._attached = True
+        if register:
+            from . import autograd_ops
+            autograd_ops.grad_ready_hooks.append(self.on_grad_ready)
+        return self
+
+    def detach(self):
+        from . import autograd_ops
+        if self.on_grad_ready in autograd_ops.grad_ready_hooks:
+            autograd_ops.grad_ready_hooks.remove(self.on_grad_ready)
+        self._attached = False
+
+    def _launch(self, b):
+        self._launched[b] = True
+        self._pending.append(dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def on_grad_ready(self, param):
+        k = id(param)
+        if not self._attached or world_size() == 1 or k not in self._pbuckets:
+            return
+        self._counts[k] = self._counts.get(k, 0) + 1
+        if self._expected is None or self._counts[k] != self._expected.get(k, 0):
+            return                                  # calibration step, or more slices of this parameter to come
+        for b in self._pbuckets[k]:
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0 and not self._launched[b]:
+                self._launch(b)
+
+    def _arm(self):
+        self._counts = {}
+        self._launched = [False] * len(self.buckets)
+        self._remaining = [0] * len(self.buckets)
+        for k, n in self._expected.items():
+            if n > 0:
+                for b in self._pbuckets[k]:
+                    self._remaining[b] += 1
+
+    # ---- after the backward ---------------------------------------------------------------------------
     def start(self):
         if world_size() == 1:
             return
-        self._pending = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+        if not self._attached:
+            self._pending = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+            return
+        self._n_early = sum(self._launched)
+        if self._expected is None:                  # first step: learn the report counts, reduce everything now
+            self._expected = dict(self._counts)
+            self._launched = [False] * len(self.buckets)
+        for b in range(len(self.buckets)):          # whatever the backward did not complete (unused parameters, padding)
+            if not self._launched[b]:
+                self._launch(b)
 
     def finish(self) -> float:
         """Wait for the buckets; returns the factor the optimiser must scale gradients by (1/world)."""
         for w in self._pending:
             w.wait()
         self._pending = []
+        if self._attached and self._expected is not None:
+            self._arm()
         return 1.0 / world_size()
 
     def all_reduce(self) -> float:
         self.start()
         return self.finish()
+
+    @property
+    def overlapped_last_step(self) -> int:
+        """Number of buckets the most recent backward issued before ``all_reduce()`` was called (diagnostics / tests)."""
+        return getattr(self, "_n_early", 0)
 
 
 def broadcast_parameters(flat_param: torch.Tensor, src: int = 0):

@@ -68,7 +68,7 @@ def train(args):
     arena = GradArena(model.parameters())
     parallel.broadcast_parameters(arena.flat_param)
     optimizer = FusedAdam(arena, lr=args.learning_rate)
-    reducer = parallel.GradientAllReducer(arena.flat_grad)
+    reducer = parallel.GradientAllReducer(arena.flat_grad).attach(arena)     # buckets go out during the backward
     best = float("inf")
     for epoch in range(args.epochs):
         model.train()
