@@ -103,6 +103,11 @@ int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int M, int N, 
 size_t vmc_linear_wgrad_tn_workspace_bytes(int M, int N, int K);
 int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, void* workspace,
                         size_t workspace_bytes, int dtype16, void* stream);
+/* Same launch, plus the bias gradient dbias[N] = column sums of dY (f32, 16-byte aligned; NULL = vmc_linear_wgrad_tn):
+ * the dY fragments already in registers go through four more MFMAs against a ones operand, replacing a separate
+ * column-sum pass over dY (autograd of F.linear's bias, train.py:104). */
+int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx,
+                             void* workspace, size_t workspace_bytes, int dtype16, void* stream);
 
 /* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
  * 1 = 8-phase 256x256 kernel, one tile per workgroup, with the tile rows of a small last partial round (T mod 256 tiles)

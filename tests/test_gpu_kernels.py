@@ -244,3 +244,15 @@ def test_linear_wgrad_splitk_exact_integers(ops, M, N, K):
     assert torch.equal(out.cpu(), ref), f"max diff {(out.cpu() - ref).abs().max()}"
     again = ops.linear_wgrad(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), torch.full((M, N), 7.0, device=DEV))
     assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 512, 2048)])
+def test_wgrad_tn_with_bias_gradient(ops, M, N, K):
+    # the same launch also returns db = column sums of dY (ones-MFMA on the fragments already in registers)
+    dy = _ints((M, N), -2, 2, 51)
+    x = _ints((M, K), -3, 3, 52)
+    out = torch.empty(N, K, device=DEV)
+    db = torch.full((N,), 123.0, device=DEV)
+    ops.wgrad_tn(dy.to(DEV, torch.bfloat16), x.to(DEV, torch.bfloat16), out, db)
+    assert torch.equal(out.cpu(), dy.t() @ x)
+    assert torch.equal(db.cpu(), dy.sum(0))

@@ -165,25 +165,36 @@ class LinearFn(torch.autograd.Function):
                 pad = torch.zeros((M, x.shape[1]), dtype=dt16, device=dz.device)
                 pad[:, :K].copy_(dx)
                 dx = pad
-        # ---- wgrad: dW = dz^T @ x  (contraction over M; transposed operands, M zero-padded to 64) ----
-        dw = None
+        # ---- wgrad: dW = dz^T @ x (contraction over the M tokens) and, from the same launch, db = column sums of dz ----
+        dw = db = None
+        want_db = bias is not None and bias.requires_grad
+        db_done = False
         if weight.requires_grad:
             Kx = x.shape[1]
             slot = getattr(weight, "_vmc_grad", None)
             if N % 8 == 0 and Kx % 8 == 0:
-                # TN kernel on the token-major operands as they are (contraction over the M tokens)
+                # TN kernel on the token-major operands as they are
+                db_view = None
+                if want_db:
+                    bslot = getattr(bias, "_vmc_grad", None)
+                    if rows is not None:
+                        db = bslot if bslot is not None else torch.zeros_like(bias, dtype=torch.float32)
+                        db_view = db[lo:hi]
+                    else:
+                        db = db_view = _grad_out(bias, (N,))
+                    db_done = True
                 if Kx == K:
                     if rows is not None:
                         if slot is not None:
-                            ops.wgrad_tn(dz, x, slot.view(weight.shape[0], K)[lo:hi])
+                            ops.wgrad_tn(dz, x, slot.view(weight.shape[0], K)[lo:hi], db_view)
                             dw = slot
                         else:
                             dw = torch.zeros((weight.shape[0], K), dtype=torch.float32, device=dz.device)
-                            ops.wgrad_tn(dz, x, dw[lo:hi])
+                            ops.wgrad_tn(dz, x, dw[lo:hi], db_view)
                     else:
-                        dw = ops.wgrad_tn(dz, x, _grad_out(weight, (N, K)).view(N, K))
+                        dw = ops.wgrad_tn(dz, x, _grad_out(weight, (N, K)).view(N, K), db_view)
                 else:                                                                   # K-padded x (patch GEMM)
-                    full = ops.wgrad_tn(dz, x, torch.empty((N, Kx), dtype=torch.float32, device=dz.device))
+                    full = ops.wgrad_tn(dz, x, torch.empty((N, Kx), dtype=torch.float32, device=dz.device), db_view)
                     dw = full[:, :K].contiguous()
             else:
                 # odd widths: transposed operands (M zero-padded to 64) through the NT kernel
@@ -199,8 +210,7 @@ class LinearFn(torch.autograd.Function):
                     dw.view(weight.shape[0], K)[lo:hi].copy_(dwp)
                 else:
                     dw = dwp.contiguous()
-        db = None
-        if bias is not None and bias.requires_grad:
+        if want_db and not db_done:
             if N % 8:                                                                   # odd width: column sums of a padded copy
                 dzc = torch.zeros((M, (N + 7) // 8 * 8), dtype=dt16, device=dz.device)
                 dzc[:, :N].copy_(dz)

@@ -28,7 +28,8 @@ constexpr int TN_STAGES = 3;
 
 template <typename T>
 __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ C,
-                                                      int M, int N, int K, int lddy, int ldx, int tiles_k, int slices) {
+                                                      float* __restrict__ dbias, int M, int N, int K, int lddy, int ldx, int tiles_k,
+                                                      int slices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
@@ -89,6 +90,14 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient = column sums of dY = dY^T . 1: the waves that own the first 64 X columns of the first K tile feed the
+  // dY fragments they hold anyway into four more MFMAs against a ones operand (every output column then carries the sum).
+  const bool do_bias = dbias != nullptr && tk == 0 && wk == 0;
+  const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
+  f32x4 bacc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
   if (s0 < s1) {
     stage_in(s0);
     if (s0 + 1 < s1) stage_in(s0 + 1);
@@ -136,6 +145,11 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
         for (int b = 0; b < 4; ++b)
           acc[a][b] = T::mfma16(make_uint4(af[0][a][0].x, af[0][a][0].y, af[0][a][1].x, af[0][a][1].y),
                                 make_uint4(bf[0][b][0].x, bf[0][b][0].y, bf[0][b][1].x, bf[0][b][1].y), acc[a][b]);
+      if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          bacc[a] = T::mfma16(make_uint4(af[0][a][0].x, af[0][a][0].y, af[0][a][1].x, af[0][a][1].y), ones, bacc[a]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -145,6 +159,11 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
         for (int b = 0; b < 4; ++b)
           acc[a][b] = T::mfma16(make_uint4(af[1][a][0].x, af[1][a][0].y, af[1][a][1].x, af[1][a][1].y),
                                 make_uint4(bf[1][b][0].x, bf[1][b][0].y, bf[1][b][1].x, bf[1][b][1].y), acc[a][b]);
+      if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          bacc[a] = T::mfma16(make_uint4(af[1][a][0].x, af[1][a][0].y, af[1][a][1].x, af[1][a][1].y), ones, bacc[a]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -162,6 +181,16 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
         if (k < K) out[(size_t)n * K + k] = acc[a][b][j];
       }
     }
+  if (do_bias && r == 0) {        // column 0 of the ones product: rows 4g + j of each 16-row block
+    float* bo = dbias + (size_t)blockIdx.y * N;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 64 * wn + 16 * a + 4 * g + j;
+        if (n < N) bo[n] = bacc[a][j];
+      }
+  }
 }
 
 __global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int slices, size_t n4) {
@@ -186,17 +215,18 @@ static int tn_slices(int M, int N, int K) {
 }
 extern "C" size_t vmc_linear_wgrad_tn_workspace_bytes(int M, int N, int K) {
   const int s = tn_slices(M, N, K);
-  return s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+  return s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 0;      // weight slabs, then bias slabs
 }
-extern "C" int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, void* workspace,
-                                   size_t workspace_bytes, int dtype16, void* stream) {
+extern "C" int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx,
+                                        void* workspace, size_t workspace_bytes, int dtype16, void* stream) {
   if (!dY || !X || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
   if ((N % 8) || (K % 8)) return VMC_E_SHAPE;
   if ((lddy % 8) || (ldx % 8)) return VMC_E_ALIGN;
-  if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)C | (uintptr_t)workspace) & 15) return VMC_E_ALIGN;
+  if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)C | (uintptr_t)workspace | (uintptr_t)dbias) & 15) return VMC_E_ALIGN;
   const int slices = tn_slices(M, N, K);
   if (slices > 1 && (!workspace || workspace_bytes < vmc_linear_wgrad_tn_workspace_bytes(M, N, K))) return VMC_E_ARG;
   float* dst = slices > 1 ? (float*)workspace : C;
+  float* bdst = !dbias ? nullptr : (slices > 1 ? (float*)workspace + (size_t)slices * N * K : dbias);
   const int tiles_k = (K + 127) / 128;
   dim3 grid(((N + 255) / 256) * tiles_k, slices);
   hipStream_t s = (hipStream_t)stream;
@@ -209,9 +239,9 @@ extern "C" int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int 
     attr_set = true;
   }
   if (dtype16 == VMC_BF16)
-    hipLaunchKernelGGL(gemm_tn_kernel<BF16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, M, N, K, lddy, ldx, tiles_k, slices);
+    hipLaunchKernelGGL(gemm_tn_kernel<BF16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, bdst, M, N, K, lddy, ldx, tiles_k, slices);
   else if (dtype16 == VMC_F16)
-    hipLaunchKernelGGL(gemm_tn_kernel<F16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, M, N, K, lddy, ldx, tiles_k, slices);
+    hipLaunchKernelGGL(gemm_tn_kernel<F16>, grid, dim3(512), lds, s, (const uint16_t*)dY, (const uint16_t*)X, dst, bdst, M, N, K, lddy, ldx, tiles_k, slices);
   else
     return VMC_E_DTYPE;
   VMC_CHECK_LAUNCH();
@@ -219,6 +249,15 @@ extern "C" int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int 
     const size_t n4 = (size_t)N * K / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, slices, n4);
     VMC_CHECK_LAUNCH();
+    if (dbias) {
+      const size_t b4 = (size_t)N / 4;
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, s, (const float*)bdst, dbias, slices, b4);
+      VMC_CHECK_LAUNCH();
+    }
   }
   return 0;
+}
+extern "C" int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, void* workspace,
+                                   size_t workspace_bytes, int dtype16, void* stream) {
+  return vmc_linear_wgrad_bias_tn(dY, X, C, nullptr, M, N, K, lddy, ldx, workspace, workspace_bytes, dtype16, stream);
 }

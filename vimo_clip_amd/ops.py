@@ -88,14 +88,15 @@ def linear_wgrad(a: torch.Tensor, w16: torch.Tensor, out: torch.Tensor) -> torch
     return linear(a, w16, out=out)
 
 
-def wgrad_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out[N,K] (f32, contiguous, overwritten) = dy[M,N]^T @ x[M,K] (vmc_linear_wgrad_tn): no transposed copies."""
+def wgrad_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, dbias: torch.Tensor = None) -> torch.Tensor:
+    """out[N,K] (f32, contiguous, overwritten) = dy[M,N]^T @ x[M,K] (vmc_linear_wgrad_bias_tn): no transposed copies.
+    dbias[N] (f32, optional, overwritten) = column sums of dy, from the same launch."""
     M, N = dy.shape
     K = x.shape[1]
     nbytes = lib.vmc_linear_wgrad_tn_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device) if nbytes else None
-    check(lib.vmc_linear_wgrad_tn(ptr(dy), ptr(x), ptr(out), M, N, K, dy.stride(0), x.stride(0), ptr(ws), nbytes, dt(dy), stream()),
-          "linear_wgrad_tn")
+    check(lib.vmc_linear_wgrad_bias_tn(ptr(dy), ptr(x), ptr(out), ptr(dbias), M, N, K, dy.stride(0), x.stride(0), ptr(ws), nbytes, dt(dy),
+                                       stream()), "linear_wgrad_bias_tn")
     return out
 
 
