@@ -275,7 +275,10 @@ extern "C" int vmc_postnorm_fwd(const float* x, const void* branch, const float*
 #define LN_BWD_BLOCKS 512
 #define LN_BWD_MAX_CHUNKS 8  // D <= 2048 in the backward (register budget: 4 float4 arrays)
 
-template <typename T>
+// NCH = float4 chunks per lane (D <= 256 NCH): a template constant so that the per-lane register arrays have the size the
+// row needs (D = 768: 3 chunks instead of 8), which leaves room to fetch the NEXT row of this wave while the current one
+// is reduced and written (one row per wave in flight was the limit: 3.2 TB/s).
+template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
@@ -286,32 +289,52 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
   const int wave_global = blockIdx.x * 4 + wave;
   const int nwaves = gridDim.x * 4;
   const float invD = 1.0f / (float)D;
-  float4 dg[LN_BWD_MAX_CHUNKS], db[LN_BWD_MAX_CHUNKS];
+  float4 dg[NCH], db[NCH], w[NCH];
 #pragma unroll
-  for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int row = wave_global; row < rows; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    float4 g[LN_BWD_MAX_CHUNKS], xh[LN_BWD_MAX_CHUNKS];
-    float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < NCH; ++c) {
+    dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int col = c * 256 + lane * 4;
+    w[c] = col < D ? *(const float4*)(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 ngy[NCH], nxv[NCH], nad[NCH];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int row) {
+    nmu = mean[row];
+    nrs = rstd[row];
 #pragma unroll
-    for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < D) {
-        const float4 gy = load4<T>(dy, (size_t)row * D + col, dy_f32);
-        const float4 xv = load4<T>(x, (size_t)row * ldx + col, x_f32);
-        const float4 w = *(const float4*)(gamma + col);
+        ngy[c] = load4<T>(dy, (size_t)row * D + col, dy_f32);
+        nxv[c] = load4<T>(x, (size_t)row * ldx + col, x_f32);
+        if (addp) nad[c] = load4<T>(addp, (size_t)row * D + col, dx_f32);
+      }
+    }
+  };
+  if (wave_global < rows) fetch(wave_global);
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const float mu = nmu, rs = nrs;
+    float4 g[NCH], xh[NCH], ad[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) {
+        const float4 gy = ngy[c], xv = nxv[c];
+        ad[c] = nad[c];
         xh[c] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         dg[c].x += gy.x * xh[c].x; dg[c].y += gy.y * xh[c].y; dg[c].z += gy.z * xh[c].z; dg[c].w += gy.w * xh[c].w;
         db[c].x += gy.x; db[c].y += gy.y; db[c].z += gy.z; db[c].w += gy.w;
-        g[c] = make_float4(gy.x * w.x, gy.y * w.y, gy.z * w.z, gy.w * w.w);
+        g[c] = make_float4(gy.x * w[c].x, gy.y * w[c].y, gy.z * w[c].z, gy.w * w[c].w);
         s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
         s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
       }
     }
+    if (row + nwaves < rows) fetch(row + nwaves);      // next row's loads fly under the reductions and stores of this one
     s1 = wave_sum(s1) * invD;
     s2 = wave_sum(s2) * invD;
 #pragma unroll
-    for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < D) {
         float4 o;
@@ -320,8 +343,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
         o.z = rs * (g[c].z - s1 - xh[c].z * s2);
         o.w = rs * (g[c].w - s1 - xh[c].w * s2);
         if (addp) {  // fused residual-branch gradient: dx = LN'(dy) + add   (add has dx's dtype and layout)
-          const float4 ad = load4<T>(addp, (size_t)row * D + col, dx_f32);
-          o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+          o.x += ad[c].x; o.y += ad[c].y; o.z += ad[c].z; o.w += ad[c].w;
         }
         store4<T>(dx, (size_t)row * D + col, dx_f32, o);
       }
@@ -330,7 +352,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
   // block-level reduction of dgamma/dbeta partials
   float* sm = (float*)smem;
 #pragma unroll
-  for (int c = 0; c < LN_BWD_MAX_CHUNKS; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int col = c * 256 + lane * 4;
     if (col < D) {
       *(float4*)(sm + (size_t)(wave * 2 + 0) * D + col) = dg[c];
@@ -342,7 +364,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
     const int which = i / D, col = i % D;
     float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) a += sm[(size_t)(w * 2 + which) * D + col];
+    for (int w4 = 0; w4 < 4; ++w4) a += sm[(size_t)(w4 * 2 + which) * D + col];
     partial[((size_t)blockIdx.x * 2 + which) * D + col] = a;
   }
 }
@@ -382,14 +404,21 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
   const int grid = ln_bwd_grid(rows);
   const size_t lds = (size_t)8 * D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype16 == VMC_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<BF16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add, (float*)workspace,
-                       rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
-  else if (dtype16 == VMC_F16)
-    hipLaunchKernelGGL(ln_bwd_kernel<F16>, dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add, (float*)workspace,
-                       rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32);
-  else
-    return VMC_E_DTYPE;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+#define VMC_LN_BWD(NCH)                                                                                                          \
+  do {                                                                                                                           \
+    if (dtype16 == VMC_BF16)                                                                                                     \
+      hipLaunchKernelGGL((ln_bwd_kernel<BF16, NCH>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add,           \
+                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((ln_bwd_kernel<F16, NCH>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add,            \
+                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
+  } while (0)
+  if (D <= 512) VMC_LN_BWD(2);
+  else if (D <= 768) VMC_LN_BWD(3);
+  else if (D <= 1024) VMC_LN_BWD(4);
+  else VMC_LN_BWD(LN_BWD_MAX_CHUNKS);
+#undef VMC_LN_BWD
   VMC_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_reduce_strided_kernel, dim3((D + 63) / 64, 2), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
   VMC_CHECK_LAUNCH();
