@@ -20,7 +20,9 @@ __device__ inline void store4(void* base, size_t idx, bool is_f32, float4 v) {
     *(uint2*)((uint16_t*)base + idx) = make_uint2(pack2<T>(v.x, v.y), pack2<T>(v.z, v.w));
 }
 
-template <typename T>
+// NCH = float4 chunks per lane, a template constant (D <= 256 NCH): register arrays of the size the row needs, gamma / beta
+// held in registers across rows, and the next row of the wave fetched while this one is reduced and written.
+template <typename T, int NCH>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, uint16_t* __restrict__ y16,
                                                      float* __restrict__ y32, float* __restrict__ mean_out,
@@ -30,25 +32,41 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const void* __restrict__ x,
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const float invD = 1.0f / (float)D;
+  float4 g[NCH], b[NCH], nv[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    g[c] = col < D ? *(const float4*)(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b[c] = col < D ? *(const float4*)(beta + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < D) nv[c] = load4<T>(x, (size_t)row * ldx + col, x_f32);
+    }
+  };
+  if (wave_global < rows) fetch(wave_global);
   for (int row = wave_global; row < rows; row += nwaves) {
-    float4 v[LN_MAX_CHUNKS];
+    float4 v[NCH];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < D) {
-        v[c] = load4<T>(x, (size_t)row * ldx + col, x_f32);
+        v[c] = nv[c];
         s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
       }
     }
+    if (row + nwaves < rows) fetch(row + nwaves);
     const float mean = wave_sum(s) * invD;
     float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < D) {
-        const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
-        ss += (a * a + b * b) + (cc * cc + d * d);
+        const float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+        ss += (a * a + bb * bb) + (cc * cc + d * d);
       }
     }
     const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
@@ -57,16 +75,14 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const void* __restrict__ x,
       if (rstd_out) rstd_out[row] = rstd;
     }
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < D) {
-        const float4 g = *(const float4*)(gamma + col);
-        const float4 b = *(const float4*)(beta + col);
         float4 o;
-        o.x = (v[c].x - mean) * rstd * g.x + b.x;
-        o.y = (v[c].y - mean) * rstd * g.y + b.y;
-        o.z = (v[c].z - mean) * rstd * g.z + b.z;
-        o.w = (v[c].w - mean) * rstd * g.w + b.w;
+        o.x = (v[c].x - mean) * rstd * g[c].x + b[c].x;
+        o.y = (v[c].y - mean) * rstd * g[c].y + b[c].y;
+        o.z = (v[c].z - mean) * rstd * g[c].z + b[c].z;
+        o.w = (v[c].w - mean) * rstd * g[c].w + b[c].w;
         if (y16) store4<T>(y16, (size_t)row * D + col, false, o);
         if (y32) store4<T>(y32, (size_t)row * D + col, true, o);
       }
@@ -81,14 +97,22 @@ extern "C" int vmc_layernorm_fwd(const void* x, const float* gamma, const float*
   if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
   if (x_dtype != VMC_F32 && x_dtype != dtype16) return VMC_E_DTYPE;
   const int grid = grid_for((size_t)rows, 4, 256 * 8);
-  if (dtype16 == VMC_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y16, y32,
-                       mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);
-  else if (dtype16 == VMC_F16)
-    hipLaunchKernelGGL(ln_fwd_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (uint16_t*)y16, y32,
-                       mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);
-  else
-    return VMC_E_DTYPE;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+#define VMC_LN_FWD(NCH)                                                                                                     \
+  do {                                                                                                                      \
+    if (dtype16 == VMC_BF16)                                                                                                \
+      hipLaunchKernelGGL((ln_fwd_kernel<BF16, NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,          \
+                         (uint16_t*)y16, y32, mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);                    \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((ln_fwd_kernel<F16, NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,           \
+                         (uint16_t*)y16, y32, mean, rstd, rows, D, (size_t)ldx, eps, x_dtype == VMC_F32);                    \
+  } while (0)
+  if (D <= 512) VMC_LN_FWD(2);
+  else if (D <= 768) VMC_LN_FWD(3);
+  else if (D <= 1024) VMC_LN_FWD(4);
+  else if (D <= 2048) VMC_LN_FWD(8);
+  else VMC_LN_FWD(LN_MAX_CHUNKS);
+#undef VMC_LN_FWD
   VMC_CHECK_LAUNCH();
   return 0;
 }
