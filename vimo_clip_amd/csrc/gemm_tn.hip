@@ -193,9 +193,16 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int slices, size_t n4) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
+// out[i] = sum over slices of slab[s][i] (float4 per thread, fixed order: deterministic).  The bias slabs sit behind the weight
+// slabs in the workspace and are reduced by the same launch (n4b float4s into outb).
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, int slices, size_t n4,
+                                                        const float* __restrict__ bslabs, float* __restrict__ outb, size_t n4b) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4 + n4b) return;
+  if (i >= n4) {
+    i -= n4;
+    slabs = bslabs; out = outb; n4 = n4b;
+  }
   float4 s = ((const float4*)slabs)[i];
   for (int k = 1; k < slices; ++k) {
     const float4 v = ((const float4*)slabs)[(size_t)k * n4 + i];
@@ -250,14 +257,10 @@ extern "C" int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C,
     return VMC_E_DTYPE;
   VMC_CHECK_LAUNCH();
   if (slices > 1) {
-    const size_t n4 = (size_t)N * K / 4;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, slices, n4);
+    const size_t n4 = (size_t)N * K / 4, n4b = dbias ? (size_t)N / 4 : 0;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, slices, n4,
+                       (const float*)bdst, dbias, n4b);
     VMC_CHECK_LAUNCH();
-    if (dbias) {
-      const size_t b4 = (size_t)N / 4;
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, s, (const float*)bdst, dbias, slices, b4);
-      VMC_CHECK_LAUNCH();
-    }
   }
   return 0;
 }

@@ -393,23 +393,34 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
+// column sums of the [P][2][D] partials: 16 columns x 16 row groups per block (2 D / 16 blocks instead of 2 D / 64 -- the
+// 4-row-group version left the chip to 24 blocks and took longer than the LayerNorm backward it finishes)
 __global__ void __launch_bounds__(256) ln_reduce_strided_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, int P, int D) {
-  __shared__ float sm[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, which = blockIdx.y;
-  const int col = blockIdx.x * 64 + tx;
-  float a0 = 0.f, a1 = 0.f;
+  __shared__ float sm[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, which = blockIdx.y;
+  const int col = blockIdx.x * 16 + tx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < D) {
+    const float* base = partial + (size_t)which * D + col;
+    const size_t rs = (size_t)2 * D;
     int p = ty;
-    for (; p + 4 < P; p += 8) {
-      a0 += partial[((size_t)p * 2 + which) * D + col];
-      a1 += partial[((size_t)(p + 4) * 2 + which) * D + col];
+    for (; p + 48 < P; p += 64) {
+      a0 += base[(size_t)p * rs];
+      a1 += base[(size_t)(p + 16) * rs];
+      a2 += base[(size_t)(p + 32) * rs];
+      a3 += base[(size_t)(p + 48) * rs];
     }
-    for (; p < P; p += 4) a0 += partial[((size_t)p * 2 + which) * D + col];
+    for (; p < P; p += 16) a0 += base[(size_t)p * rs];
   }
-  sm[ty][tx] = a0 + a1;
+  sm[ty][tx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (ty == 0 && col < D) (which ? dbeta : dgamma)[col] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+  if (ty == 0 && col < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][tx];
+    (which ? dbeta : dgamma)[col] = t;
+  }
 }
 
 static int ln_bwd_grid(int rows) { return grid_for((size_t)rows, 4, LN_BWD_BLOCKS); }
@@ -444,7 +455,7 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
   else VMC_LN_BWD(LN_BWD_MAX_CHUNKS);
 #undef VMC_LN_BWD
   VMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_reduce_strided_kernel, dim3((D + 63) / 64, 2), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
+  hipLaunchKernelGGL(ln_reduce_strided_kernel, dim3((D + 15) / 16, 2), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, grid, D);
   VMC_CHECK_LAUNCH();
   return 0;
 }
