@@ -37,6 +37,14 @@ class _WeightCache:
         # id() values are recycled once a parameter dies: the weak reference proves it is still the same object
         if hit is not None and hit[0]() is p and hit[1] == p._version and hit[2] == p.data_ptr():
             return hit[3]
+        # a parameter that is being trained needs both copies every step (forward + dgrad): one launch makes both.
+        # (pad_k is by construction "contraction length % 64 != 0" at every call site, which is what cast_weight_both pads.)
+        if p.requires_grad and torch.is_grad_enabled() and p.dim() == 2 and pad_k == ((p.shape[0] if transposed else p.shape[1]) % 64 != 0):
+            w, wt = ops.cast_weight_both(p, dtype16)
+            ident = (weakref.ref(p), p._version, p.data_ptr())
+            self._c[(id(p), dtype16, False, p.shape[1] % 64 != 0)] = ident + (w,)
+            self._c[(id(p), dtype16, True, p.shape[0] % 64 != 0)] = ident + (wt,)
+            return wt if transposed else w
         w = ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
         self._c[key] = (weakref.ref(p), p._version, p.data_ptr(), w)
         return w

@@ -34,6 +34,21 @@ def cast_weight(w: torch.Tensor, dtype16: torch.dtype, transposed: bool = False,
     return out
 
 
+def cast_weight_both(w: torch.Tensor, dtype16: torch.dtype):
+    """One launch for both 16-bit copies a training step needs: [rows, cols(+pad to 64)] for the forward and the
+    transposed [cols, rows(+pad to 64)] for the dgrad (K padding only where the contraction length is not a multiple of 64)."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    if w2.dtype != torch.float32 or not w2.is_contiguous():
+        w2 = w2.float().contiguous()
+    rows, cols = w2.shape
+    ld = _kpad(cols) if cols % 64 else cols
+    ldt = _kpad(rows) if rows % 64 else rows
+    out = (torch.zeros if ld != cols else torch.empty)((rows, ld), dtype=dtype16, device=w.device)
+    out_t = (torch.zeros if ldt != rows else torch.empty)((cols, ldt), dtype=dtype16, device=w.device)
+    check(lib.vmc_cast_weight(ptr(w2), ptr(out), ptr(out_t), rows, cols, ld, ldt, dt(dtype16), stream()), "cast_weight")
+    return out, out_t
+
+
 def cast16(x: torch.Tensor, dtype16: torch.dtype) -> torch.Tensor:
     if x.dtype == dtype16:
         return x
