@@ -29,7 +29,7 @@ class _WeightCache:
     def __init__(self):
         self._c = {}
 
-    def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False):
+    def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False, both=False):
         if not isinstance(p, torch.nn.Parameter):      # temporaries (e.g. row slices of in_proj_weight) are not cached
             return ops.cast_weight(p, dtype16, transposed=transposed, pad_k=pad_k)
         key = (id(p), dtype16, transposed, pad_k)
@@ -39,7 +39,7 @@ class _WeightCache:
             return hit[3]
         # a parameter that is being trained needs both copies every step (forward + dgrad): one launch makes both.
         # (pad_k is by construction "contraction length % 64 != 0" at every call site, which is what cast_weight_both pads.)
-        if p.requires_grad and torch.is_grad_enabled() and p.dim() == 2 and pad_k == ((p.shape[0] if transposed else p.shape[1]) % 64 != 0):
+        if both and p.requires_grad and p.dim() == 2 and pad_k == ((p.shape[0] if transposed else p.shape[1]) % 64 != 0):
             w, wt = ops.cast_weight_both(p, dtype16)
             ident = (weakref.ref(p), p._version, p.data_ptr())
             self._c[(id(p), dtype16, False, p.shape[1] % 64 != 0)] = ident + (w,)
@@ -98,7 +98,7 @@ class LinearFn(torch.autograd.Function):
         dt16 = x.dtype
         K = weight[0].numel()
         ctx.rows = rows
-        w16 = weights.get(weight, dt16, pad_k=(K % 64 != 0))
+        w16 = weights.get(weight, dt16, pad_k=(K % 64 != 0), both=not inference)   # training: the dgrad copy in the same launch
         if rows is not None:
             w16 = w16[rows[0]:rows[1]]
         ctx.x_cols = x.shape[1]
