@@ -195,6 +195,30 @@ def test_extendable_append_resume_and_commit_consistency(tmp_path):
             assert hf["clip2/embeddings"].shape == (74, E) and np.all(hf["clip2/embeddings"][71:] == 5.0)
 
 
+def test_lzf_declared_datasets(tmp_path):
+    # inference_frame_diff.py:243 defaults to compression="lzf" (h5py's own filter, id 32000).  h5lite declares the filter and
+    # stores every chunk raw with the filter-skipped bit, as h5py does for chunks LZF cannot shrink: stock libhdf5 (no plugin)
+    # and h5lite read it back; a genuinely LZF-compressed chunk (hand-built stream) decodes through the reader as well.
+    p = str(tmp_path / "lzf.h5")
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((70, 16)).astype(np.float32)
+    with h5.File(p, "w") as hf:
+        d = hf.create_dataset("e", shape=(0, 16), maxshape=(None, 16), chunks=(32, 16), dtype="float32", compression="lzf")
+        for lo in (0, 32, 64):
+            hi = min(70, lo + 32)
+            d.resize((hi, 16))
+            d[lo:hi] = a[lo:hi]
+    with h5.File(p, "r") as hf:
+        assert hf["e"].compression == "lzf" and np.array_equal(hf["e"][:], a)
+    if REF is not None:
+        f = REF.open(p)
+        assert np.array_equal(REF.read(f, "/e"), a)
+        REF.close(f)
+    raw = bytes(range(40)) * 3                                         # literal run + back-references (offset 40)
+    stream = bytes([31]) + raw[:32] + bytes([7]) + raw[32:40] + bytes([(7 << 5) | 0, 80 - 9, 39])
+    assert h5._lzf_decompress(stream, 120) == raw
+
+
 def test_space_is_reused_across_commits(tmp_path):
     p = str(tmp_path / "reuse.h5")
     with h5.File(p, "w") as hf:
@@ -219,7 +243,7 @@ def test_api_errors(tmp_path):
         with pytest.raises(TypeError):
             hf["a"].resize((4, 3))                                     # contiguous datasets do not resize
         with pytest.raises(ValueError):
-            hf.create_dataset("z", shape=(4,), dtype="float32", compression="lzf")
+            hf.create_dataset("z", shape=(4,), dtype="float32", compression="szip")
         d = hf.create_dataset("b", shape=(2, 3), maxshape=(4, 3), dtype="int32")
         with pytest.raises(ValueError):
             d.resize((5, 3))

@@ -96,7 +96,7 @@ def test_streaming_export_resume_errors_and_layout(tmp_path):
     out = str(tmp_path / "out" / "emb.h5")
     model = _StubStudent()
     with pytest.warns(UserWarning, match="Error on bad"):
-        stats = inf.export_embeddings(paths[:3], model, out, chunk_size=32, flush_interval_s=0)
+        stats = inf.export_embeddings(paths[:3], model, out, chunk_size=32, flush_interval_s=0, compression="gzip")
     assert stats == {"processed": 2, "skipped_existing": 0, "skipped_low_ram": 0, "errors": 1}
     assert model.calls == [32, 32, 6, 5]
     with h5.File(out, "r") as f:

@@ -8,9 +8,11 @@ group attributes ``total_frames`` / ``original_frames`` (+ ``error`` / ``skipped
 
 The file layout written is the "earliest" HDF5 format that h5py produces by default: superblock v0, symbol-table groups
 (v1 B-tree + local heap), v1 object headers, layout v3 (contiguous / chunked with a v1 chunk B-tree), filter pipeline v1
-(deflate), attribute messages v1, global heap for variable-length strings.  The reader accepts the same (plus
-continuation blocks, superblock v1, compact layout, fixed-length strings, shuffle + deflate, lzf-free files).  Files in
-the "latest" format (superblock >= 2, fractal heaps) raise NotImplementedError.
+(deflate), attribute messages v1, global heap for variable-length strings.  The reader accepts the same plus
+continuation blocks, superblock v1, compact layout, fixed-length strings, shuffle / fletcher32 / deflate / h5py-LZF
+chunks and per-chunk filter masks.  ``compression="lzf"`` on write declares h5py's filter and stores the chunks raw with
+the filter-skipped mask (see ``Dataset._create``).  Files in the "latest" format (superblock >= 2, fractal heaps) raise
+NotImplementedError.
 
 The API mirrors the h5py subset the reference calls: ``File(path, mode)`` as a context manager, ``keys / in / [] /
 create_group / require_group / create_dataset(shape=, maxshape=, chunks=, compression=, dtype=, data=) / attrs / flush``,
@@ -448,10 +450,11 @@ class Dataset(_Node):
             d.maxshape = d.shape
         if compression is True:
             compression = "gzip"
-        if compression not in (None, "gzip"):
-            raise ValueError(f"h5lite writes gzip or uncompressed data; compression={compression!r} is read-only")
+        if compression not in (None, "gzip", "lzf"):
+            raise ValueError(f"h5lite writes gzip, lzf-declared or uncompressed data; got compression={compression!r}")
         if compression == "gzip":
             d._filters = [(1, [4 if compression_opts is None else int(compression_opts)])]
+        lzf = compression == "lzf"
         need_chunks = compression is not None or d.maxshape != d.shape
         if chunks is True or (chunks is None and need_chunks):
             chunks = cls._guess_chunks(d.shape, d.maxshape, d._dt.itemsize)
@@ -460,6 +463,12 @@ class Dataset(_Node):
             if len(chunks) != len(d.shape) or any(c <= 0 for c in chunks):
                 raise ValueError("chunk shape must be positive and match the dataset rank")
             d.chunks, d._index, d._layout = chunks, {}, ("chunked", None)
+            if lzf:
+                # h5py's LZF filter (id 32000; client data: filter revision 4, liblzf 0x0105, chunk bytes).  h5lite does not
+                # compress through it: every chunk is stored raw with the filter's bit set in the chunk's filter mask, which
+                # is exactly what h5py writes whenever LZF cannot shrink a chunk (float embeddings) -- readable by h5py and,
+                # because skipped filters are never invoked, by a stock libhdf5 without the plugin.
+                d._filters = [(32000, [4, 0x0105, int(np.prod(chunks)) * d._dt.itemsize])]
         else:
             d._layout = ("contiguous", UNDEF, 0)
         if data is not None and data.size:
@@ -498,13 +507,17 @@ class Dataset(_Node):
                 raise NotImplementedError(f"HDF5 filter {fid}")
         return raw
 
-    def _encode_chunk(self, raw: bytes) -> bytes:
-        for fid, cd in self._filters:
+    def _encode_chunk(self, raw: bytes):
+        """-> (stored bytes, filter mask): bit k of the mask set = filter k of the pipeline was skipped for this chunk."""
+        mask = 0
+        for k, (fid, cd) in enumerate(self._filters):
             if fid == 1:
                 raw = zlib.compress(raw, cd[0] if cd else 4)
+            elif fid == 32000:
+                mask |= 1 << k                  # stored uncompressed (see _create)
             else:
                 raise NotImplementedError(f"writing through HDF5 filter {fid}")
-        return raw
+        return raw, mask
 
     def _elem_size(self):
         if self._dt == _VLEN_STR:
@@ -716,12 +729,12 @@ class Dataset(_Node):
                 else:
                     block = np.zeros(ch, dtype=self._dt)
                 block[tuple(dst)] = value[tuple(src)]
-            raw = self._encode_chunk(np.ascontiguousarray(block).tobytes())
+            raw, fmask = self._encode_chunk(np.ascontiguousarray(block).tobytes())
             if off in idx:
                 f._free_later(idx[off][0], idx[off][1])
             addr = f._alloc(len(raw))
             f._pwrite(addr, raw)
-            idx[off] = (addr, len(raw), 0)
+            idx[off] = (addr, len(raw), fmask)
         self._touch()
 
 
@@ -1224,7 +1237,7 @@ class File(Group):
             if d._filters:
                 fb = struct.pack("<BB6x", 1, len(d._filters))
                 for fid, cd in d._filters:
-                    fname = _pad8(b"deflate\0") if fid == 1 else b""
+                    fname = _pad8(b"deflate\0") if fid == 1 else (_pad8(b"lzf\0") if fid == 32000 else b"")
                     fb += struct.pack("<HHHH", fid, len(fname), 1, len(cd)) + fname + b"".join(struct.pack("<I", c) for c in cd)
                     if len(cd) % 2:
                         fb += b"\0" * 4

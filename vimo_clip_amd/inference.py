@@ -79,7 +79,7 @@ class _Committer:
 
 
 @torch.no_grad()
-def process_and_write_video_incremental(video_path, model, h5f, chunk_size=256, min_free_gb=0.0, compression="gzip",
+def process_and_write_video_incremental(video_path, model, h5f, chunk_size=256, min_free_gb=0.0, compression="lzf",
                                         frame_source=None, commit=None):
     """inference_frame_diff.py:235-312.  Returns the final ``(T, D)`` shape."""
     video_id = os.path.splitext(os.path.basename(video_path))[0]
@@ -111,7 +111,7 @@ def process_and_write_video_incremental(video_path, model, h5f, chunk_size=256, 
 
 @torch.no_grad()
 def export_embeddings(video_paths, model, output_h5_path, resume=False, overwrite=False, chunk_size=256, min_free_gb=0.0,
-                      compression="gzip", frame_source=None, flush_interval_s=5.0, streaming=True):
+                      compression="lzf", frame_source=None, flush_interval_s=5.0, streaming=True):
     """Main loop of inference_frame_diff.py:318-410 (``streaming=True``) or inference.py:94-114 (``streaming=False``: the
     whole video in one forward, plain contiguous ``embeddings`` dataset, file rewritten from scratch).
     Returns ``{"processed", "skipped_existing", "skipped_low_ram", "errors"}``."""
