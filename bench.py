@@ -237,13 +237,43 @@ def main():
                 events.append((s, e, 2.0 * a.shape[0] * w16.shape[0] * w16.shape[1], a.shape[0] * w16.shape[0] >= 192 * 65536))
                 return r
 
-            ops.linear = timed_linear
+            # the two other kernels of a ViT layer, against their own bounds: add+LayerNorm (HBM: x fp32 read + write, 16-bit
+            # branch in, 16-bit h out = 12 B / element) and attention (HBM: q/k/v read + o write = 8 B per token-channel of D)
+            sec_events = {"add_ln": [], "attention": []}
+            orig_addln, orig_attn = ops.add_layernorm_, ops.attention_vit
+
+            def timed_addln(x32, b16, gm, bt, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig_addln(x32, b16, gm, bt, **kw)
+                e.record()
+                rows = kw.get("rows") or x32.numel() // gm.shape[0]
+                sec_events["add_ln"].append((s, e, 12.0 * rows * gm.shape[0], rows * gm.shape[0] >= (1 << 24)))
+                return r
+
+            def timed_attn(qkv, F_, N_, H_, *pa, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig_attn(qkv, F_, N_, H_, *pa, **kw)
+                e.record()
+                sec_events["attention"].append((s, e, 8.0 * F_ * N_ * H_ * 64, True))
+                return r
+
+            ops.linear, ops.add_layernorm_, ops.attention_vit = timed_linear, timed_addln, timed_attn
             try:
                 for _ in range(args.steps):
                     step()
                 torch.cuda.synchronize()
             finally:
-                ops.linear = orig_linear
+                ops.linear, ops.add_layernorm_, ops.attention_vit = orig_linear, orig_addln, orig_attn
+            sec = {}
+            for name, evs in sec_events.items():
+                sel = [(s.elapsed_time(e) * 1e-3, b) for s, e, b, big_ in evs if big_]
+                if sel:
+                    t_, b_ = sum(t for t, _ in sel), sum(b for _, b in sel)
+                    sec[name] = {"bound": "hbm", "achieved": round(b_ / t_ / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(b_ / t_ / 8e12, 4), "launches": len(sel), "avg_launch_ms": round(1e3 * t_ / len(sel), 4)}
+            result["secondary_rooflines"] = sec
             big = [(s.elapsed_time(e) * 1e-3, f) for s, e, f, is_big in events if is_big]
             t_big = sum(t for t, _ in big)
             f_big = sum(f for _, f in big)
