@@ -300,3 +300,28 @@ def test_full_size_tfam_batch_properties():
     ref = otfam.amo_clip_forward(sd, rgb[pick], mot[pick], mr[pick], mf[pick], nhead=H)
     err = (full[pick].cpu() - ref).abs().max().item()
     assert err <= TOL[torch.bfloat16] * max(1.0, ref.abs().max().item()), err
+
+
+def test_tfam_graphed_eval_matches_eager_and_is_reused():
+    # hipGraph replay of the evaluation forward: same kernels, same bits as the eager forward; one graph per batch shape
+    from vimo_clip_amd.TFAM.data.dataset import SyntheticEmbeddingDataset, collate_fn_pad
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    from vimo_clip_amd.TFAM.train_and_eval import Config, GraphedEvalForward, ModelTester
+    cfg = Config(num_classes=24, d_model=256, nhead=4, num_layers=2, dim_feedforward=512, batch_size=8, dropout=0.0, mlp_dropout=0.0,
+                 device="cuda:0", use_graphs=True)
+    m = AMO_CLIP(d_model=256, nhead=4, num_layers=2, dim_feedforward=512, num_classes=24, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda().eval()
+    m.load_state_dict(synth.tfam_state_dict(256, 4, 2, 512, 24, 3), strict=True)
+    fixed = SyntheticEmbeddingDataset(synth.multi_hot_labels(3, "y", 64, 24), 256, tmin=16, tmax=16, seed=9)      # num_frames=16 loaders
+    ragged = SyntheticEmbeddingDataset(synth.multi_hot_labels(3, "y", 64, 24), 256, tmin=5, tmax=40, seed=9)
+    for ds, max_graphs in ((fixed, 1), (ragged, 8)):
+        gf = GraphedEvalForward(m, cfg)
+        for s in range(0, 64, 8):
+            batch = collate_fn_pad([ds[i] for i in range(s, s + 8)])
+            with torch.no_grad():
+                ref = m(batch["embeddings"].cuda(), batch["flow_embeddings"].cuda(), mask_rgb=batch["mask_rgb"].cuda(), mask_flow=batch["mask_flow"].cuda())
+            assert torch.equal(gf(batch), ref)
+        assert 1 <= len(gf._graphs) <= max_graphs
+    mAP_g, _ = ModelTester(m, fixed, cfg).evaluate()
+    cfg.use_graphs = False
+    mAP_e, _ = ModelTester(m, fixed, cfg).evaluate()
+    assert mAP_g == mAP_e

@@ -33,7 +33,7 @@ class Config:
         self.num_classes, self.d_model, self.nhead, self.num_layers, self.dim_feedforward = 140, 512, 8, 4, 2048
         self.use_cross_attention, self.use_only_rgb, self.use_only_flow, self.use_pe, self.concat_dim = True, False, False, False, 1
         self.dropout, self.mlp_dropout, self.device, self.checkpoint_dir, self.log_dir = 0.1, 0.1, "cuda", "checkpoints", "logs"
-        self.task, self.motion_key = "multilabel", "flow"
+        self.task, self.motion_key, self.use_graphs = "multilabel", "flow", False    # use_graphs: hipGraph replay of the eval forward
         self.class_names_dir = self.train_dataset_path = self.val_dataset_path = self.frame_diff_dataset_path = None
         self.__dict__.update(kw)
 
@@ -94,6 +94,44 @@ def _model_forward(model, batch, config):
                  mask_flow=batch[f"mask_{mk}"].to(dev))
 
 
+class GraphedEvalForward:
+    """Evaluation forward as hipGraph replays.  At the reference's batch size (8 clips) a forward is ~90 kernels of a few
+    microseconds: launch bound.  One graph per distinct (B, T_rgb, T_motion) shape, captured on first sight; the reference
+    pools with ``x.mean(dim=1)`` over the padded length (AMO_CLIP.py:169), so a batch cannot be padded further to share a
+    graph without changing its logits -- ``bucket`` therefore defaults to 1 (exact shapes: fixed-length loaders, e.g.
+    ``num_frames=16``, replay one graph; ragged loaders fill ``max_graphs`` and fall back to eager launches).  Only for
+    ``model.eval()`` under ``no_grad`` (no dropout, no optimiser state inside the graph)."""
+
+    def __init__(self, model, config, bucket=1, max_graphs=32):
+        self.model, self.config, self.bucket, self.max_graphs = model, config, bucket, max_graphs
+        self._graphs = {}
+
+    def _pad(self, x, T):
+        if x.shape[1] == T:
+            return x
+        out = torch.zeros((x.shape[0], T) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        out[:, :x.shape[1]] = x
+        return out
+
+    def __call__(self, batch):
+        from ..graphs import GraphedCallable
+        dev, mk, bk = self.config.device, self.config.motion_key, self.bucket
+        rgb, mot = batch["embeddings"].to(dev), batch[f"{mk}_embeddings"].to(dev)
+        mr, mf = batch["mask_rgb"].to(dev), batch[f"mask_{mk}"].to(dev)
+        Tr, Tf = -(-rgb.shape[1] // bk) * bk, -(-mot.shape[1] // bk) * bk
+        key = (rgb.shape[0], Tr, Tf, rgb.shape[2])
+        if key not in self._graphs and len(self._graphs) >= self.max_graphs:
+            return self.model(rgb, mot, mask_rgb=mr, mask_flow=mf)              # too many shapes: eager
+        rgb, mot, mr, mf = self._pad(rgb, Tr), self._pad(mot, Tf), self._pad(mr, Tr), self._pad(mf, Tf)
+        g = self._graphs.get(key)
+        if g is None:
+            def fwd(a, b, c, d):
+                with torch.no_grad():
+                    return self.model(a, b, mask_rgb=c, mask_flow=d)
+            g = self._graphs[key] = GraphedCallable(fwd, rgb, mot, mr, mf)
+        return g(rgb, mot, mr, mf).clone()
+
+
 class ModelTrainer:
     def __init__(self, model, train_set, val_set, config, rank=0, world=1):
         self.model, self.train_set, self.val_set, self.config, self.rank, self.world = model, train_set, val_set, config, rank, world
@@ -105,6 +143,7 @@ class ModelTrainer:
         self.optimizer = FusedAdam(self.arena, lr=1e-4, weight_decay=0.1, decoupled=True)       # lr hard-coded as :53
         self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.epochs, eta_min=1e-6)
         self.reducer = parallel.GradientAllReducer(self.arena.flat_grad).attach(self.arena)   # buckets go out during the backward
+        self._graphed_eval = GraphedEvalForward(model, config) if getattr(config, "use_graphs", False) else None
 
     def _forward(self, batch):
         return _model_forward(self.model, batch, self.config), batch["labels"].to(self.config.device)
@@ -132,7 +171,10 @@ class ModelTrainer:
         total, n = torch.zeros((), device=self.config.device), 0
         with torch.no_grad():
             for batch in batches(self.val_set, self.config.batch_size, self.rank, self.world, motion_key=self.config.motion_key):
-                output, labels = self._forward(batch)
+                if self._graphed_eval is not None:
+                    output, labels = self._graphed_eval(batch), batch["labels"].to(self.config.device)
+                else:
+                    output, labels = self._forward(batch)
                 total += self.criterion(output, labels)
                 n += 1
                 self.mAP_metric.update(output, labels.to(dtype=torch.int))
@@ -164,6 +206,7 @@ class ModelTester:
     def __init__(self, model, test_set, config, rank=0, world=1):
         self.model, self.test_set, self.config, self.rank, self.world = model, test_set, config, rank, world
         _, self.mAP_metric = task_objects(config)
+        self._graphed_eval = GraphedEvalForward(model, config) if getattr(config, "use_graphs", False) else None
 
     def evaluate(self, k=5):
         """sigmoid top-k predictions + micro mAP (:193-248)."""
@@ -171,7 +214,7 @@ class ModelTester:
         results, dev = {}, self.config.device
         with torch.no_grad():
             for batch in batches(self.test_set, self.config.batch_size, self.rank, self.world, motion_key=self.config.motion_key):
-                out = _model_forward(self.model, batch, self.config)
+                out = self._graphed_eval(batch) if self._graphed_eval is not None else _model_forward(self.model, batch, self.config)
                 self.mAP_metric.update(out, batch["labels"].to(dev).to(torch.int))
                 probs = torch.sigmoid(out) if self.config.task == "multilabel" else torch.softmax(out, dim=1)
                 top = torch.topk(probs, k, dim=1)
