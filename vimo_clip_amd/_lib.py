@@ -107,5 +107,13 @@ def ptr(t) -> int | None:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  The raw C getters cost ~1 us per call;
+    ``torch.cuda.current_stream().cuda_stream`` builds a Stream object (~9 us), which was 14 % of a launch-bound step."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
