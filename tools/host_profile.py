@@ -43,4 +43,4 @@ for _ in range(100):
     step()
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
