@@ -151,6 +151,13 @@ int vmc_add_layernorm_fwd(float* x, const void* branch, const float* gamma, cons
  * (y16, next GEMM operand); optional saves for the backward: sum_out = s, mean, rstd.  D % 256 == 0, D <= 2048. */
 int vmc_postnorm_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
                      void* y16, float* mean, float* rstd, int rows, int D, float eps, int dtype16, void* stream);
+/* The same tail with the branch passed through one or two dropouts first: LN(x + drop2(drop1(branch))) -- the FFN's trailing
+ * nn.Dropout and the block's own dropout (AMO_CLIP.py:28,50; :40,45 for the attention tails).  Masks are vmc_dropout's
+ * counter-based masks on the flat element index (same seed -> same mask), so the backward can regenerate them.
+ * drop_p2 > 0 requires drop_p1 > 0. */
+int vmc_postnorm_dropout_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
+                             void* y16, float* mean, float* rstd, int rows, int D, float eps, float drop_p1,
+                             uint64_t drop_seed1, float drop_p2, uint64_t drop_seed2, int dtype16, void* stream);
 /* Backward (autograd of the LayerNorms, train.py:104): dx [rows,D] (f32 or 16-bit per dx_dtype) =
  * LN'(dy) + add, where `add` (optional, dx's dtype/layout) is the gradient arriving over the residual
  * branch that forks at x (fused so the fork needs no separate add pass).  dgamma/dbeta f32 [D],

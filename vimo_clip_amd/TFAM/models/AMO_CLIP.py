@@ -74,12 +74,18 @@ class AttentionLayer(nn.Module):
         H, D = self.num_heads, self.d_model
         tr = self.training
         p = self.p if tr else 0.0
-        fused = D % 256 == 0 and D <= 2048
+        fused = D % 256 == 0 and D <= 2048 and getattr(self, "fuse_tail", True)   # fuse_tail=False: separate dropout / add / LN (tests)
 
-        def tail(xr, branch, norm):           # LN(x + dropout(branch)) -> (fp32, 16-bit)
+        def tail(xr, branch, norm, extra_drop=False):   # LN(x + dropout(branch)) -> (fp32, 16-bit)
+            # extra_drop: the branch first passes the FFN's own trailing nn.Dropout (:28), then the block dropout (:50)
+            if fused:      # dropout masks applied inside the add + LayerNorm kernel (same seeds / masks as ag.dropout would use)
+                d1 = (p, seed_fn()) if p > 0 and extra_drop else None
+                d2 = (p, seed_fn()) if p > 0 else None
+                drops = (d1, d2) if d1 else ((d2, (0.0, 0)) if d2 else ((0.0, 0), (0.0, 0)))
+                return ag.postnorm(xr, branch, norm.weight, norm.bias, drops)
+            if extra_drop:
+                branch = ag.dropout(branch, p, tr, seed_fn)
             branch = ag.dropout(branch, p, tr, seed_fn)
-            if fused:
-                return ag.postnorm(xr, branch, norm.weight, norm.bias)
             y = ag.layernorm(_add32(xr, branch, dt16), norm.weight, norm.bias, dt16, out_f32=True)
             a, b2 = ag.fork(y, dt16)
             return a, ag.cast(b2, dt16)
@@ -98,8 +104,7 @@ class AttentionLayer(nn.Module):
         h = ag.linear(x16, self.ffn[0].weight, self.ffn[0].bias, act=self.ffn_act)
         h = ag.dropout(h, p, tr, seed_fn)
         f = ag.linear(h, self.ffn[3].weight, self.ffn[3].bias)
-        f = ag.dropout(f, p, tr, seed_fn)                                  # ffn's own trailing Dropout (:28); self.dropout (:50) is in tail()
-        return tail(x32, f, self.norm_ffn)
+        return tail(x32, f, self.norm_ffn, extra_drop=True)                # ffn's trailing Dropout (:28) + self.dropout (:50), both in tail()
 
 
 class _Add32(torch.autograd.Function):

@@ -282,10 +282,11 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class PostNormFn(torch.autograd.Function):
-    """(y32, y16) = LN(x32 + branch16): the tail of a post-norm block in one kernel (vmc_postnorm_fwd)."""
+    """(y32, y16) = LN(x32 + drop2(drop1(branch16))): the tail of a post-norm block in one kernel (vmc_postnorm_dropout_fwd).
+    ``drops`` = ((p1, seed1), (p2, seed2)) with p = 0 for "no dropout"."""
 
     @staticmethod
-    def forward(ctx, x32, branch, gamma, beta, need):
+    def forward(ctx, x32, branch, gamma, beta, need, drops=((0.0, 0), (0.0, 0))):
         D = gamma.shape[0]
         rows = x32.numel() // D
         dev = x32.device
@@ -294,10 +295,12 @@ class PostNormFn(torch.autograd.Function):
         ssum = torch.empty((rows, D), dtype=torch.float32, device=dev) if need else None
         mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
-        check(lib.vmc_postnorm_fwd(ptr(x32), ptr(branch), ptr(gamma.detach()), ptr(beta.detach()), ptr(ssum), ptr(y32), ptr(y16),
-                                   ptr(mean), ptr(rstd), rows, D, 1e-5, dt(branch), stream()), "postnorm_fwd")
+        (p1, s1), (p2, s2) = drops
+        check(lib.vmc_postnorm_dropout_fwd(ptr(x32), ptr(branch), ptr(gamma.detach()), ptr(beta.detach()), ptr(ssum), ptr(y32), ptr(y16),
+                                           ptr(mean), ptr(rstd), rows, D, 1e-5, float(p1), int(s1), float(p2), int(s2), dt(branch),
+                                           stream()), "postnorm_dropout_fwd")
         ctx.save_for_backward(ssum, mean, rstd)
-        ctx.gamma, ctx.beta, ctx.dt16 = gamma, beta, branch.dtype
+        ctx.gamma, ctx.beta, ctx.dt16, ctx.drops = gamma, beta, branch.dtype, drops
         return y32, y16
 
     @staticmethod
@@ -318,11 +321,17 @@ class PostNormFn(torch.autograd.Function):
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=ssum.device)
         check(lib.vmc_layernorm_bwd(ptr(dy), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
                                     rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
-        return dsum, ops.cast16(dsum, dt16), _deliver(gamma, dg), _deliver(beta, db), None
+        (p1, s1), (p2, s2) = ctx.drops
+        dbr = ops.cast16(dsum, dt16)
+        if p1 > 0.0:        # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds (in place on the 16-bit copy)
+            check(lib.vmc_dropout(ptr(dbr), ptr(dbr), dbr.numel(), float(p1), int(s1), dt(dbr), dt(dt16), stream()), "dropout")
+            if p2 > 0.0:
+                check(lib.vmc_dropout(ptr(dbr), ptr(dbr), dbr.numel(), float(p2), int(s2), dt(dbr), dt(dt16), stream()), "dropout")
+        return dsum, dbr, _deliver(gamma, dg), _deliver(beta, db), None, None
 
 
-def postnorm(x32, branch, gamma, beta):
-    return PostNormFn.apply(x32, branch, gamma, beta, torch.is_grad_enabled())
+def postnorm(x32, branch, gamma, beta, drops=((0.0, 0), (0.0, 0))):
+    return PostNormFn.apply(x32, branch, gamma, beta, torch.is_grad_enabled(), drops)
 
 
 def layernorm(x, gamma, beta, dt16, passthrough=False, out_f32=False):

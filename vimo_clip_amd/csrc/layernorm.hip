@@ -209,7 +209,10 @@ template <typename T, int CH>
 __global__ void __launch_bounds__(256) postnorm_kernel(const float* __restrict__ x, const uint16_t* __restrict__ branch,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ sum_out, float* __restrict__ y32, uint16_t* __restrict__ y16,
-                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, float eps) {
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, float eps,
+                                                       float p1, uint64_t seed1, float p2, uint64_t seed2) {
+  // p1 / p2 > 0: the branch goes through one or two dropouts first (nn.Dropout after the FFN's second Linear and the
+  // block's own dropout, AMO_CLIP.py:28,50) -- same counter-based masks as vmc_dropout on the flat element index
   constexpr int D = CH * 256;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -235,6 +238,15 @@ __global__ void __launch_bounds__(256) postnorm_kernel(const float* __restrict__
       float a0, a1, a2, a3;
       unpack2<T>(br[c].x, a0, a1);
       unpack2<T>(br[c].y, a2, a3);
+      if (p1 > 0.f) {
+        const uint64_t e = base + c * 256;
+        a0 *= dropout_factor(p1, seed1, e); a1 *= dropout_factor(p1, seed1, e + 1);
+        a2 *= dropout_factor(p1, seed1, e + 2); a3 *= dropout_factor(p1, seed1, e + 3);
+        if (p2 > 0.f) {
+          a0 *= dropout_factor(p2, seed2, e); a1 *= dropout_factor(p2, seed2, e + 1);
+          a2 *= dropout_factor(p2, seed2, e + 2); a3 *= dropout_factor(p2, seed2, e + 3);
+        }
+      }
       v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
       s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
       if (sum_out) *(float4*)(sum_out + base + c * 256) = v[c];
@@ -264,11 +276,12 @@ __global__ void __launch_bounds__(256) postnorm_kernel(const float* __restrict__
 
 template <typename T>
 static int launch_postnorm(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
-                           void* y16, float* mean, float* rstd, int rows, int D, float eps, hipStream_t s) {
+                           void* y16, float* mean, float* rstd, int rows, int D, float eps, float p1, uint64_t seed1, float p2,
+                           uint64_t seed2, hipStream_t s) {
   const int grid = grid_for((size_t)rows, 4, 256 * 8);
 #define VMC_PN(CHN)                                                                                                          \
   hipLaunchKernelGGL((postnorm_kernel<T, CHN>), dim3(grid), dim3(256), 0, s, x, (const uint16_t*)branch, gamma, beta, sum_out, y32, \
-                     (uint16_t*)y16, mean, rstd, rows, eps)
+                     (uint16_t*)y16, mean, rstd, rows, eps, p1, seed1, p2, seed2)
   switch (D / 256) {
     case 1: VMC_PN(1); break;
     case 2: VMC_PN(2); break;
@@ -283,13 +296,24 @@ static int launch_postnorm(const float* x, const void* branch, const float* gamm
   return 0;
 }
 
-extern "C" int vmc_postnorm_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
-                                void* y16, float* mean, float* rstd, int rows, int D, float eps, int dtype16, void* stream) {
+extern "C" int vmc_postnorm_dropout_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out,
+                                        float* y32, void* y16, float* mean, float* rstd, int rows, int D, float eps, float drop_p1,
+                                        uint64_t drop_seed1, float drop_p2, uint64_t drop_seed2, int dtype16, void* stream) {
   if (!x || !branch || !gamma || !beta || (!y32 && !y16) || rows <= 0 || D <= 0) return VMC_E_ARG;
   if (D % 256 || D > 2048) return VMC_E_SHAPE;
-  if (dtype16 == VMC_BF16) return launch_postnorm<BF16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, (hipStream_t)stream);
-  if (dtype16 == VMC_F16) return launch_postnorm<F16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, (hipStream_t)stream);
+  if (drop_p1 < 0.f || drop_p1 >= 1.f || drop_p2 < 0.f || drop_p2 >= 1.f || (drop_p2 > 0.f && drop_p1 <= 0.f)) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16)
+    return launch_postnorm<BF16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, drop_p1, drop_seed1, drop_p2,
+                                 drop_seed2, (hipStream_t)stream);
+  if (dtype16 == VMC_F16)
+    return launch_postnorm<F16>(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, drop_p1, drop_seed1, drop_p2,
+                                drop_seed2, (hipStream_t)stream);
   return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_postnorm_fwd(const float* x, const void* branch, const float* gamma, const float* beta, float* sum_out, float* y32,
+                                void* y16, float* mean, float* rstd, int rows, int D, float eps, int dtype16, void* stream) {
+  return vmc_postnorm_dropout_fwd(x, branch, gamma, beta, sum_out, y32, y16, mean, rstd, rows, D, eps, 0.f, 0, 0.f, 0, dtype16, stream);
 }
 
 // ---- backward ---------------------------------------------------------------------------------
