@@ -141,7 +141,11 @@ __global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, cons
     uint2 br[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      v[c] = *(const float4*)(x + (size_t)row * ldx + c * 256 + lane * 4);
+      {   // streaming (non-temporal): x is next touched by the following add+LN, ~1 GB of GEMM traffic later; keeping it out
+          // of the caches leaves them to the 16-bit branch just written by the GEMM and to h, which the next GEMM re-reads
+        const f32x4 t = __builtin_nontemporal_load((const f32x4*)(x + (size_t)row * ldx + c * 256 + lane * 4));
+        v[c] = make_float4(t[0], t[1], t[2], t[3]);
+      }
       br[c] = *(const uint2*)(branch + (size_t)row * ldb + c * 256 + lane * 4);
     }
     float s = 0.f;
@@ -152,7 +156,10 @@ __global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, cons
       unpack2<T>(br[c].y, a2, a3);
       v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
       s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-      if (write_x) *(float4*)(x + (size_t)row * ldx + c * 256 + lane * 4) = v[c];
+      if (write_x) {
+        const f32x4 t = {v[c].x, v[c].y, v[c].z, v[c].w};
+        __builtin_nontemporal_store(t, (f32x4*)(x + (size_t)row * ldx + c * 256 + lane * 4));
+      }
     }
     const float mean = wave_sum(s) * (1.0f / D);
     float ss = 0.f;
