@@ -348,13 +348,17 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) {
     // Round quantisation: T tiles on 256 CUs cost ceil(T/256) tile-times.  When the last, partial round holds only a few
-    // tiles that are whole tile rows (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4),
-    // those rows go to the small-tile kernel, which spreads them over the whole chip, in a second launch.
+    // tiles (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4; student ViT-B/32: 100 x 3 tiles ->
+    // 44 tiles in a second round), the tile rows that do not fit the full rounds go to the small-tile kernels, which spread
+    // them over the whole chip, in a second launch.
     const int tm = (M + 255) / 256, tn = (N + 255) / 256;
-    const long tail = t256 % 256;
-    if (vmc_gemm_variant() == 1 && !out_row_group && !res_row_mod && t256 >= 512 && tail > 0 && tail <= 64 &&
-        tail % tn == 0) {
-      const int m_main = (tm - (int)(tail / tn)) * 256;
+    // whole tile rows that fit in the full rounds (a last main round may leave up to tn - 1 CUs idle); the rest is the tail
+    const int rounds = (int)(t256 / 256);
+    const int main_rows = rounds > 0 ? (rounds * 256) / tn : 0;
+    const long tail = (long)(tm - main_rows) * tn;              // tiles handed to the small-tile kernel
+    if (vmc_gemm_variant() == 1 && !out_row_group && !res_row_mod && main_rows > 0 && main_rows < tm && t256 % 256 != 0 &&
+        tail <= (rounds >= 2 ? 64 : 96)) {
+      const int m_main = main_rows * 256;
       GemmArgs t = g;
       g.M = m_main;
       int rc = vmc_gemm8_launch(g, act, dtype16, (hipStream_t)stream);
