@@ -130,8 +130,11 @@ class LinearFn(torch.autograd.Function):
                 raise ValueError("LinearFn: activation and residual are not combined on this path")
             if inference:                          # no graph is being built: activation fused into the GEMM epilogue
                 return crop(ops.linear(x, w16, bias=b, act=act, out_dtype=torch.float32 if out_f32 else dt16))
-            z = crop(ops.linear(x, w16, bias=b))
-            y = ops.act_fwd(z, act)
+            if act == ops.ACT_RELU:                # relu'(z) = [z > 0] = [y > 0]: the fused output doubles as the saved "z"
+                z = y = crop(ops.linear(x, w16, bias=b, act=act))
+            else:
+                z = crop(ops.linear(x, w16, bias=b))
+                y = ops.act_fwd(z, act)
             if out_f32:
                 y = ops.cast32(y)
         else:
