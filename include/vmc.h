@@ -87,6 +87,14 @@ int vmc_linear(const void* A, const void* W, const float* bias, const void* res,
                int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                int dtype16, void* stream);
+/* vmc_linear with a side output for training: Z[m, n] (16-bit, row stride ldz >= N, ldz % 4 == 0, 16-byte aligned) receives
+ * A W^T + bias BEFORE the activation, from the same epilogue that writes C = alpha * act(.) (+ res) -- the tensor the backward
+ * of an activation needs (autograd of the QuickGELU / GELU linears, models/student_model.py:27-34, clip model.py MLP), without
+ * a second pass over the 4D-wide matrix.  Z == NULL: identical to vmc_linear.  Not combined with out_row_group. */
+int vmc_linear_preact(const void* A, const void* W, const float* bias, const void* res, void* C, void* Z,
+                      int M, int N, int K, int lda, int ldw, int ldc, int ldres, int ldz,
+                      int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                      int dtype16, void* stream);
 
 /* Weight-gradient form of vmc_linear (autograd of F.linear w.r.t. the weight, train.py:104): C [M,N] f32 contiguous =
  * A [M,K] @ W [N,K]^T with a long contraction K (the token count) and a small output.  128x128 tiles x K slices; every

@@ -256,3 +256,17 @@ def test_wgrad_tn_with_bias_gradient(ops, M, N, K):
     ops.wgrad_tn(dy.to(DEV, torch.bfloat16), x.to(DEV, torch.bfloat16), out, db)
     assert torch.equal(out.cpu(), dy.t() @ x)
     assert torch.equal(db.cpu(), dy.sum(0))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(65792, 1024, 128, 1), (25600, 768, 256, 2), (300, 96, 64, 1), (4096, 512, 128, 3), (777, 264, 192, 1)])
+def test_linear_preact_side_output(ops, M, N, K, act):
+    # vmc_linear_preact: C = act(A W^T + b) and Z = A W^T + b from one epilogue (8-phase interior tiles, its 256-row tail,
+    # the small-tile kernels and ragged edges) == the two separate launches
+    a = (_ints((M, K), -2, 2, 61) * 0.25).to(DEV, torch.bfloat16)
+    w = (_ints((N, K), -2, 2, 62) * 0.25).to(DEV, torch.bfloat16)
+    bias = (_ints((N,), -3, 3, 63) * 0.5).to(DEV)
+    z_ref = ops.linear(a, w, bias=bias)
+    y_ref = ops.linear(a, w, bias=bias, act=act)
+    z = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    y = ops.linear(a, w, bias=bias, act=act, z_out=z)
+    assert torch.equal(z, z_ref) and torch.equal(y, y_ref)

@@ -27,6 +27,7 @@ SIGNATURES = {
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
     "vmc_resample_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
+    "vmc_linear_preact": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
     "vmc_linear_splitk_workspace_bytes": (Z, [I, I, I]),
     "vmc_linear_splitk_f32": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
     "vmc_linear_wgrad_tn_workspace_bytes": (Z, [I, I, I]),

@@ -132,6 +132,9 @@ class LinearFn(torch.autograd.Function):
                 return crop(ops.linear(x, w16, bias=b, act=act, out_dtype=torch.float32 if out_f32 else dt16))
             if act == ops.ACT_RELU:                # relu'(z) = [z > 0] = [y > 0]: the fused output doubles as the saved "z"
                 z = y = crop(ops.linear(x, w16, bias=b, act=act))
+            elif w16.shape[0] == Nw:               # one launch: y = act(z) and the pre-activation z as a side output
+                z = torch.empty((x.shape[0], Nw), dtype=dt16, device=x.device)
+                y = ops.linear(x, w16, bias=b, act=act, z_out=z)
             else:
                 z = crop(ops.linear(x, w16, bias=b))
                 y = ops.act_fwd(z, act)

@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
         const float4 b = *(const float4*)(g.bias + col);
         x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
       }
+      if (g.zout) *(uint2*)((uint16_t*)g.zout + (size_t)orow * g.ldz + col) = make_uint2(pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]));
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = g.alpha * apply_act<ACT>(x[j]);
       if (g.res) {
@@ -328,7 +329,16 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
                           int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                           int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                           int dtype16, void* stream) {
+  return vmc_linear_preact(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
+                           res_row_mod, dtype16, stream);
+}
+
+extern "C" int vmc_linear_preact(const void* A, const void* W, const float* bias, const void* res, void* C, void* Z,
+                                 int M, int N, int K, int lda, int ldw, int ldc, int ldres, int ldz,
+                                 int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                                 int dtype16, void* stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
+  if (Z && (ldz < N || (ldz % 4) || ((uintptr_t)Z & 15) || out_row_group)) return VMC_E_ARG;
   if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
   if (K % 64 != 0 || N % 4 != 0) return VMC_E_SHAPE;
   if (lda % 8 || ldw % 8 || ldc % 4 || (res && (ldres % 4))) return VMC_E_ALIGN;
@@ -343,6 +353,7 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
   g.out_row_group = out_row_group; g.res_row_mod = res_row_mod;
   g.tiles_m = g.tiles_n = 0;
   g.k_slices = 1;
+  g.zout = (char*)Z; g.ldz = ldz;
   // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
   // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -367,6 +378,7 @@ extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const
       t.A += (size_t)m_main * lda * 2;
       t.C += (size_t)m_main * ldc * (t.out_f32 ? 4 : 2);
       if (t.res) t.res += (size_t)m_main * ldres * (t.res_f32 ? 4 : 2);
+      if (t.zout) t.zout += (size_t)m_main * ldz * 2;
       if (dtype16 == VMC_BF16) return launch_act<BF16>(t, act, (hipStream_t)stream);
       return launch_act<F16>(t, act, (hipStream_t)stream);
     }
@@ -421,6 +433,7 @@ extern "C" int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = N; g.ldres = 0;
   g.alpha = 1.0f; g.out_f32 = 1; g.res_f32 = 0; g.out_row_group = 0; g.res_row_mod = 0;
   g.k_slices = slices;
+  g.zout = nullptr; g.ldz = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype16 == VMC_BF16 ? launch_cfg<BF16, VMC_ACT_NONE, 4, 2, 2>(g, s)
            : dtype16 == VMC_F16 ? launch_cfg<F16, VMC_ACT_NONE, 4, 2, 2>(g, s) : VMC_E_DTYPE;

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   const bool vec8 = gemm_vec8_ok(g);
   // Interior tile writing 16-bit rows without residual / row remap (qkv, c_fc, dgrad): branch-free epilogue, the bias of
   // this lane's 2 x 8 columns loaded once instead of once per row (the generic path below cannot hoist it past the stores).
-  if (vec8 && !g.out_f32 && !g.res && !g.out_row_group && m0 + 256 <= g.M && n0 + 256 <= g.N) {
+  if (vec8 && !g.out_f32 && !g.res && !g.out_row_group && (!g.zout || (g.ldz & 7) == 0) && m0 + 256 <= g.M && n0 + 256 <= g.N) {
     float bv[2][8];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
@@ -222,6 +222,7 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
       }
     }
     uint16_t* cbase = (uint16_t*)g.C + (size_t)(m0 + 64 * wm + r) * g.ldc + n0 + 32 * wn + 8 * q;
+    uint16_t* zbase = g.zout ? (uint16_t*)g.zout + (size_t)(m0 + 64 * wm + r) * g.ldz + n0 + 32 * wn + 8 * q : nullptr;
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -232,7 +233,12 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * nt + j] = g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][j] + bv[nh][4 * nt + j]);
+            for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mh][nh][mt][nt][j] + bv[nh][4 * nt + j];
+          if (zbase)     // pre-activation side output for the backward (training)
+            *(uint4*)(zbase + (size_t)(128 * mh + 16 * mt) * g.ldz + 128 * nh) =
+                make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
           *(uint4*)(cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh) =
               make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
         }
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   }
   // Interior tile accumulating into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of
   // four tile rows are fetched together (8 x 32 B per lane in flight), then added and stored; no per-row branches.
-  if (vec8 && g.out_f32 && g.res && g.res_f32 && !g.out_row_group && !g.res_row_mod && m0 + 256 <= g.M && n0 + 256 <= g.N) {
+  if (vec8 && g.out_f32 && g.res && g.res_f32 && !g.zout && !g.out_row_group && !g.res_row_mod && m0 + 256 <= g.M && n0 + 256 <= g.N) {
     float bv[2][8];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {

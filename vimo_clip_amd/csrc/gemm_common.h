@@ -14,6 +14,8 @@ struct GemmArgs {
   int out_f32, res_f32;
   int out_row_group, res_row_mod;
   int tiles_m, tiles_n;
+  char* zout;     // optional 16-bit side output [M, ldz]: the value before the activation (bias included) -- what the backward of
+  int ldz;        // act(x W^T + b) needs, written by the same epilogue instead of a second pass (vmc_linear_preact)
   int k_slices;   // > 1: split-K (gemm_kernel only): blockIdx.y owns a K range and atomically adds into the f32 output
 };
 
@@ -32,6 +34,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmArgs& g, int row, in
       const float4 b = *(const float4*)(g.bias + col);
       x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
     }
+    if (g.zout) *(uint2*)((uint16_t*)g.zout + (size_t)orow * g.ldz + col) = make_uint2(pack2<T>(x[0], x[1]), pack2<T>(x[2], x[3]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = g.alpha * apply_act<ACT>(x[j]);
     if (g.res) {

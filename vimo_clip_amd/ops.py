@@ -69,8 +69,9 @@ def cast32(x: torch.Tensor) -> torch.Tensor:
 
 def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = ACT_NONE, alpha: float = 1.0,
            out_dtype=None, out=None, out_row_group: int = 0, res_row_mod: int = 0, out_rows=None,
-           lda=None) -> torch.Tensor:
-    """C = alpha * act(A @ W^T + bias) + res   (vmc_linear).  a: [M,K] 16-bit (row stride lda), w16: [N,K]."""
+           lda=None, z_out=None) -> torch.Tensor:
+    """C = alpha * act(A @ W^T + bias) + res   (vmc_linear).  a: [M,K] 16-bit (row stride lda), w16: [N,K].
+    z_out: optional 16-bit [M,N] tensor that receives A @ W^T + bias before the activation (vmc_linear_preact)."""
     M = a.shape[0]
     K = w16.shape[1]
     N = w16.shape[0]
@@ -82,6 +83,11 @@ def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = A
         out = torch.empty((out_rows or M, N), dtype=out_dtype, device=a.device)
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("linear: bias must be float32")
+    if z_out is not None:
+        check(lib.vmc_linear_preact(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), ptr(z_out), M, N, K, lda, w16.stride(0), out.stride(0),
+                                    res.stride(0) if res is not None else 0, z_out.stride(0), act, float(alpha), dt(out),
+                                    dt(res) if res is not None else 0, out_row_group, res_row_mod, dt(a), stream()), "linear_preact")
+        return out
     check(lib.vmc_linear(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), M, N, K, lda, w16.stride(0), out.stride(0),
                          res.stride(0) if res is not None else 0, act, float(alpha), dt(out), dt(res) if res is not None else 0,
                          out_row_group, res_row_mod, dt(a), stream()), "linear")
