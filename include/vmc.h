@@ -117,11 +117,15 @@ int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, i
 int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx,
                              void* workspace, size_t workspace_bytes, int dtype16, void* stream);
 
-/* Tuning knob for vmc_linear's large-problem kernel (A/B measurements in one process): 0 = two-stage tiles only,
- * 1 = 8-phase 256x256 kernel, one tile per workgroup, with the tile rows of a small last partial round (T mod 256 tiles)
- * handed to the small-tile kernel in a second launch (default), 2 = persistent 8-phase kernel, 3 = as 1 without the
- * tail-row split.  Results are identical bit for bit across all of them. */
-int vmc_set_gemm_variant(int variant);
+/* vmc_linear with the large-problem kernel chosen PER CALL (A/B measurements in one process; the library keeps no
+ * state): VMC_GEMM_TWOSTAGE = two-stage tiles only, VMC_GEMM_DEFAULT = what vmc_linear does (8-phase 256x256 kernel,
+ * one tile per workgroup, the tile rows of a small last partial round handed to the small-tile kernel in a second
+ * launch), VMC_GEMM_NO_TAIL_SPLIT = the same without that split.  Results are identical bit for bit across them. */
+enum { VMC_GEMM_TWOSTAGE = 0, VMC_GEMM_DEFAULT = 1, VMC_GEMM_NO_TAIL_SPLIT = 2, VMC_GEMM_VARIANTS = 3 };
+int vmc_linear_variant(const void* A, const void* W, const float* bias, const void* res, void* C,
+                       int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                       int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                       int dtype16, int variant, void* stream);
 
 /* 16-bit 2-D transpose  out[c, r] = in[r, c]  (rows x cols, element strides ld_in / ld_out); used for
  * the dgrad/wgrad operand layouts of K8 (autograd of F.linear, train.py:104). */
@@ -269,6 +273,53 @@ int vmc_bce_loss(const float* logits, const float* targets, float* loss, float* 
  * workspace >= vmc_loss_workspace_bytes(rows). */
 int vmc_cross_entropy_loss(const float* logits, const long long* target_index, const float* target_prob, float* loss,
                            float* dlogits, int rows, int C, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K11-K14 fused — the TFAM forward as a chain of weight-streaming launches for short clips (T, Tk <= 32,
+ * d_model 512 / 768, head_dim 64 / 96): AttentionLayer.forward (TFAM/models/AMO_CLIP.py:37-51) in 6 launches
+ * with the LayerNorms, both attentions, bias / ReLU / residual adds and casts in prologues and epilogues;
+ * the K|V projections of ALL layers' cross attention hoisted into one GEMM over the raw motion tokens
+ * (:43-45 projects the same tokens in every layer); mean-pool over all T rows + classifier (:84,:170).
+ * Eval-mode arithmetic (dropout = identity).  Shapes outside the supported set return VMC_E_SHAPE and the
+ * caller uses the per-op entry points above.
+ *
+ * Weights are read from two packs the caller fills once per weight version (vmc_cast_weight / plain copies into
+ * the offsets vmc_tfam_pack_offset returns):
+ *   wpack  16-bit: per layer self_attn.in_proj_weight [3D,D] | self_attn.out_proj.weight | cross_attn.in_proj_weight[0:D]
+ *          | cross_attn.out_proj.weight | ffn.0.weight [ff,D] | ffn.3.weight [D,ff]; then, for l = 0..L-1,
+ *          cross_attn.in_proj_weight[D:3D] of layer l ([L*2D, D] in all) | classifier.1.weight | classifier.4.weight
+ *   ppack  fp32: per layer the six biases in the same order, norm_self / norm_cross / norm_ffn (weight then bias);
+ *          then in_proj_bias[D:3D] per layer | classifier.0 weight, bias | classifier.1.bias | classifier.4.bias
+ * vmc_tfam_pack_offset(slot, layer, ...) = element offset of a slot (16-bit elements for W slots, floats for P slots;
+ * `layer` is ignored by the global slots except KV_ALL, where it selects that layer's 2D rows); *_END = pack size.
+ */
+enum {
+  VMC_TFAM_W_SELF_IN = 0, VMC_TFAM_W_SELF_OUT, VMC_TFAM_W_CROSS_Q, VMC_TFAM_W_CROSS_OUT, VMC_TFAM_W_FFN0, VMC_TFAM_W_FFN3,
+  VMC_TFAM_W_KV_ALL, VMC_TFAM_W_CLS1, VMC_TFAM_W_CLS4, VMC_TFAM_W_END,
+  VMC_TFAM_P_SELF_IN_B = 16, VMC_TFAM_P_SELF_OUT_B, VMC_TFAM_P_CROSS_Q_B, VMC_TFAM_P_CROSS_OUT_B, VMC_TFAM_P_FFN0_B,
+  VMC_TFAM_P_FFN3_B, VMC_TFAM_P_NORM_SELF, VMC_TFAM_P_NORM_CROSS, VMC_TFAM_P_NORM_FFN, VMC_TFAM_P_KV_ALL_B,
+  VMC_TFAM_P_CLS_LN, VMC_TFAM_P_CLS1_B, VMC_TFAM_P_CLS4_B, VMC_TFAM_P_END
+};
+long long vmc_tfam_pack_offset(int slot, int layer, int D, int ff, int L, int C);
+/* Scratch for one forward of B clips (activations of one layer at a time + the hoisted K|V); caller-owned. */
+size_t vmc_tfam_workspace_bytes(int B, int T, int Tk, int D, int ff, int L, int C, int has_cross);
+/* Hoisted cross-attention K|V: ws.kv[B*Tk, L*2D] = motion[B*Tk, D] (fp32) x kv_all^T + bias  (AMO_CLIP.py:43-45, all layers). */
+int vmc_tfam_kv_fwd(const float* motion, const void* wpack, const float* ppack, void* workspace, size_t workspace_bytes,
+                    int B, int T, int Tk, int D, int H, int ff, int L, int C, int dtype16, void* stream);
+/* One AttentionLayer (AMO_CLIP.py:37-51).  Layer 0 reads the fp32 tokens x_in [B*T, D]; later layers (x_in = NULL)
+ * continue from the pre-LayerNorm sum the previous layer left in the workspace.  mask [B,T] / mask_kv [B,Tk]: 1 = real
+ * token (the reference's mask_rgb / mask_flow before inversion, :125-126), NULL = all real.  has_cross = 0: self
+ * attention + FFN only (rgb-only / flow-only / concatenated-token modes, :136-147,:159-167). */
+int vmc_tfam_layer_fwd(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv, const void* wpack, const float* ppack,
+                       int layer, void* workspace, size_t workspace_bytes, int B, int T, int Tk, int D, int H, int ff, int L,
+                       int C, int has_cross, int dtype16, void* stream);
+/* logits[B, C] (fp32) = classifier(mean over all T rows of LN_ffn(last layer))  (AMO_CLIP.py:84,:170). */
+int vmc_tfam_head_fwd(const void* wpack, const float* ppack, float* logits, void* workspace, size_t workspace_bytes,
+                      int B, int T, int Tk, int D, int H, int ff, int L, int C, int has_cross, int dtype16, void* stream);
+/* kv + L layers + head in one call (AMO_CLIP.forward, :99-171, eval mode). */
+int vmc_tfam_forward(const float* x, const float* motion, const uint8_t* mask, const uint8_t* mask_kv, const void* wpack,
+                     const float* ppack, float* logits, void* workspace, size_t workspace_bytes, int B, int T, int Tk,
+                     int D, int H, int ff, int L, int C, int has_cross, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K15 — fused Adam / AdamW over one flat fp32 buffer (train.py:66; TFAM/train_and_eval.py:53).

@@ -12,7 +12,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, "include", "vmc.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(vmc_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|long long|const char\*)\s+(vmc_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n

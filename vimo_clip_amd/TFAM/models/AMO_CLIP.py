@@ -183,6 +183,7 @@ class AMO_CLIP(nn.Module):
         self.classifier = nn.Sequential(_LN(d_model), _linear_init(_Lin(d_model, d_model // 2)), _Slot(), _Slot(),
                                         _linear_init(_Lin(d_model // 2, num_classes)))
         self.projection_layer = _linear_init(_Lin(2 * d_model, d_model))
+        self.fused_inference = True     # eval + no_grad forwards of short clips run the fused launch chain (tfam_fused.py)
         self.set_dropout_seed(0x5EED)
 
     def set_dropout_seed(self, seed: int):
@@ -215,6 +216,40 @@ class AMO_CLIP(nn.Module):
                 out.append(p)
         return out
 
+    def _forward_fused(self, rgb_emb, motion_emb, m_rgb, m_flow):
+        """Eval forward through vmc_tfam_forward (one call: hoisted K|V GEMM + 6 launches per layer + pool + head).
+        Returns None when the shapes are outside the fused chain's set; the per-op path below then runs."""
+        from ... import tfam_fused as tf
+        dt16 = self.compute_dtype
+
+        def f32(t):
+            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+        motion, m_kv, cross = None, None, False
+        if self.use_only_rgb:
+            x, m = rgb_emb, m_rgb
+        elif self.use_only_flow:
+            x, m = motion_emb, m_flow
+        elif self.use_cross_attention:
+            x, m, motion, m_kv, cross = rgb_emb, m_rgb, motion_emb, m_flow, True
+        else:
+            rgb_cut = rgb_emb[:, :-1, :]
+            m_cut = m_rgb[:, :-1] if m_rgb is not None else None
+            if self.concat_dim == 1:
+                x = torch.cat([rgb_cut, motion_emb], dim=1)                   # token concat: memory plumbing
+                m = torch.cat([m_cut, m_flow], dim=1).contiguous() if m_cut is not None else None
+            else:
+                xcat = torch.cat([rgb_cut, motion_emb], dim=-1)
+                if not tf.supported(self, xcat.shape[0], xcat.shape[1], 0, False):
+                    return None
+                x = ag.linear(ag.cast(f32(xcat).view(-1, xcat.shape[-1]), dt16), self.projection_layer.weight,
+                              self.projection_layer.bias, out_f32=True).view(xcat.shape[0], xcat.shape[1], -1)
+                m = m_flow
+        if x.shape[-1] != self.d_model or not tf.supported(self, x.shape[0], x.shape[1], motion.shape[1] if cross else 0, cross):
+            return None
+        pack = tf.get_pack(self, dt16).refresh()
+        return pack.forward(f32(x), f32(motion) if cross else None, m, m_kv, cross)
+
     def forward(self, rgb_emb, motion_emb, mask_rgb=None, mask_flow=None):
         dt16, D = self.compute_dtype, self.d_model
         dev = self.device
@@ -227,6 +262,10 @@ class AMO_CLIP(nn.Module):
         m_rgb = mask_rgb.to(device=dev, dtype=torch.uint8).contiguous() if mask_rgb is not None else None
         m_flow = mask_flow.to(device=dev, dtype=torch.uint8).contiguous() if mask_flow is not None else None
         seed_fn = self._next_seed
+        if self.fused_inference and not self.training and not torch.is_grad_enabled():
+            out = self._forward_fused(rgb_emb, motion_emb, m_rgb, m_flow)
+            if out is not None:
+                return out
 
         def flat(t):
             return t.contiguous().float().view(-1, t.shape[-1])

@@ -33,7 +33,7 @@ SIGNATURES = {
     "vmc_linear_wgrad_tn_workspace_bytes": (Z, [I, I, I]),
     "vmc_linear_wgrad_tn": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
     "vmc_linear_wgrad_bias_tn": (I, [P, P, P, P, I, I, I, I, I, P, Z, I, P]),
-    "vmc_set_gemm_variant": (I, [I]),
+    "vmc_linear_variant": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, P]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),
     "vmc_colsum_workspace_bytes": (Z, [I, I]),
@@ -65,6 +65,12 @@ SIGNATURES = {
     "vmc_distill_loss": (I, [P, P, P, P, I, I, I, Z, I, P, Z, P]),
     "vmc_bce_loss": (I, [P, P, P, P, I, F, P, Z, P]),
     "vmc_cross_entropy_loss": (I, [P, P, P, P, P, I, I, P, Z, P]),
+    "vmc_tfam_pack_offset": (ctypes.c_longlong, [I, I, I, I, I, I]),
+    "vmc_tfam_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
+    "vmc_tfam_kv_fwd": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_tfam_layer_fwd": (I, [P, P, P, P, P, I, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_tfam_head_fwd": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_tfam_forward": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
     "vmc_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, I, F, P]),
     "vmc_sumsq": (I, [P, Z, P, P]),
 }

@@ -28,6 +28,7 @@ ACT_NONE = ops.ACT_NONE
 class _WeightCache:
     def __init__(self):
         self._c = {}
+        self.epoch = 0          # bumped whenever the masters may have changed behind autograd's version counters
 
     def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False, both=False):
         if not isinstance(p, torch.nn.Parameter):      # temporaries (e.g. row slices of in_proj_weight) are not cached
@@ -51,6 +52,7 @@ class _WeightCache:
 
     def clear(self):
         self._c.clear()
+        self.epoch += 1
 
 
 weights = _WeightCache()

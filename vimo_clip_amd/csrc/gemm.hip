@@ -313,30 +313,40 @@ static int launch_act(GemmArgs& g, int act, hipStream_t stream) {
   return VMC_E_ARG;
 }
 
-static int g_gemm_variant = []() {
-  const char* e = getenv("VMC_GEMM8");
-  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
-}();
-int vmc_gemm_variant() { return g_gemm_variant; }
-
-extern "C" int vmc_set_gemm_variant(int v) {
-  if (v < 0 || v > 3) return VMC_E_ARG;
-  g_gemm_variant = v;
-  return 0;
-}
+static int linear_impl(const void* A, const void* W, const float* bias, const void* res, void* C, void* Z,
+                       int M, int N, int K, int lda, int ldw, int ldc, int ldres, int ldz,
+                       int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                       int dtype16, int variant, void* stream);
 
 extern "C" int vmc_linear(const void* A, const void* W, const float* bias, const void* res, void* C,
                           int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                           int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                           int dtype16, void* stream) {
-  return vmc_linear_preact(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
-                           res_row_mod, dtype16, stream);
+  return linear_impl(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
+                     res_row_mod, dtype16, VMC_GEMM_DEFAULT, stream);
+}
+
+extern "C" int vmc_linear_variant(const void* A, const void* W, const float* bias, const void* res, void* C,
+                                  int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                                  int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                                  int dtype16, int variant, void* stream) {
+  if (variant < 0 || variant >= VMC_GEMM_VARIANTS) return VMC_E_ARG;
+  return linear_impl(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
+                     res_row_mod, dtype16, variant, stream);
 }
 
 extern "C" int vmc_linear_preact(const void* A, const void* W, const float* bias, const void* res, void* C, void* Z,
                                  int M, int N, int K, int lda, int ldw, int ldc, int ldres, int ldz,
                                  int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                                  int dtype16, void* stream) {
+  return linear_impl(A, W, bias, res, C, Z, M, N, K, lda, ldw, ldc, ldres, ldz, act, alpha, out_dtype, res_dtype, out_row_group,
+                     res_row_mod, dtype16, VMC_GEMM_DEFAULT, stream);
+}
+
+static int linear_impl(const void* A, const void* W, const float* bias, const void* res, void* C, void* Z,
+                       int M, int N, int K, int lda, int ldw, int ldc, int ldres, int ldz,
+                       int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
+                       int dtype16, int variant, void* stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VMC_E_ARG;
   if (Z && (ldz < N || (ldz % 4) || ((uintptr_t)Z & 15) || out_row_group)) return VMC_E_ARG;
   if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
@@ -355,9 +365,10 @@ extern "C" int vmc_linear_preact(const void* A, const void* W, const float* bias
   g.k_slices = 1;
   g.zout = (char*)Z; g.ldz = ldz;
   // large problems with an even K-tile count take the 8-phase 256x256 kernel (gemm8.hip);
-  // VMC_GEMM8=0 in the environment forces the two-stage kernels (A/B measurements).
+  // variant VMC_GEMM_TWOSTAGE forces the two-stage kernels (A/B measurements through vmc_linear_variant).
+  g.variant = variant;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (vmc_gemm_variant() != 0 && t256 >= 192 && (K % 128) == 0) {
+  if (variant != VMC_GEMM_TWOSTAGE && t256 >= 192 && (K % 128) == 0) {
     // Round quantisation: T tiles on 256 CUs cost ceil(T/256) tile-times.  When the last, partial round holds only a few
     // tiles (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4; student ViT-B/32: 100 x 3 tiles ->
     // 44 tiles in a second round), the tile rows that do not fit the full rounds go to the small-tile kernels, which spread
@@ -367,7 +378,7 @@ extern "C" int vmc_linear_preact(const void* A, const void* W, const float* bias
     const int rounds = (int)(t256 / 256);
     const int main_rows = rounds > 0 ? (rounds * 256) / tn : 0;
     const long tail = (long)(tm - main_rows) * tn;              // tiles handed to the small-tile kernel
-    if (vmc_gemm_variant() == 1 && !out_row_group && !res_row_mod && main_rows > 0 && main_rows < tm && t256 % 256 != 0 &&
+    if (variant != VMC_GEMM_NO_TAIL_SPLIT && !out_row_group && !res_row_mod && main_rows > 0 && main_rows < tm && t256 % 256 != 0 &&
         tail <= (rounds >= 2 ? 64 : 96)) {
       const int m_main = main_rows * 256;
       GemmArgs t = g;
@@ -433,6 +444,7 @@ extern "C" int vmc_linear_splitk_f32(const void* A, const void* W, float* C, int
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = N; g.ldres = 0;
   g.alpha = 1.0f; g.out_f32 = 1; g.res_f32 = 0; g.out_row_group = 0; g.res_row_mod = 0;
   g.k_slices = slices;
+  g.variant = VMC_GEMM_DEFAULT;
   g.zout = nullptr; g.ldz = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype16 == VMC_BF16 ? launch_cfg<BF16, VMC_ACT_NONE, 4, 2, 2>(g, s)

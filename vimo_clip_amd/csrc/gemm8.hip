@@ -311,204 +311,6 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
 }
 
 
-// ==================================================================================================
-// Persistent variant (vmc_set_gemm_variant(2)): 256 workgroups (one per CU) walk the tile list of their XCD
-// group; the LDS-DMA pipeline runs straight through tile boundaries: the last K-tile pair of output tile j
-// stages the first 1.5 K tiles of tile j+1 (exactly the prologue set, into the slots the schedule would use
-// anyway), so the workgroup relaunch and the pipeline fill disappear and the epilogue stores overlap the next
-// tile's loads.  Same global_load_lds addressing as gemm8_kernel; the per-thread source pointers are switched
-// to the next tile in the middle of the roll-over iteration, right after the last current-tile stage.
-// (A first version staged through buffer_load ... lds with scalar offsets; its main loop measured 6-11 % slower.)
-// ==================================================================================================
-__device__ __forceinline__ void g8_set_ptrs(const GemmArgs& g, int tid, int m0, int n0, const char* (&sA0)[2], const char* (&sA1)[2],
-                                            const char* (&sB0)[2], const char* (&sB1)[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row, ch;
-    stage_src_x(i * 512 + tid, row, ch);
-    sA0[i] = g.A + ((size_t)min(m0 + row, g.M - 1) * g.lda + ch * 8) * 2;
-    sA1[i] = g.A + ((size_t)min(m0 + 128 + row, g.M - 1) * g.lda + ch * 8) * 2;
-    stage_src_w8(i * 512 + tid, row, ch);
-    sB0[i] = g.W + ((size_t)min(n0 + row, g.N - 1) * g.ldw + ch * 8) * 2;
-    sB1[i] = g.W + ((size_t)min(n0 + 128 + row, g.N - 1) * g.ldw + ch * 8) * 2;
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void g8q_iter(char* A0e, char* A1e, char* B0e, char* B1e, char* A0o, char* A1o, char* B0o, char* B1o,
-                                         const char* (&sA0)[2], const char* (&sA1)[2], const char* (&sB0)[2], const char* (&sB1)[2],
-                                         size_t k1, size_t k2, size_t k3, int wave_lds, const int (&xoff)[2], const int (&woff)[2][2],
-                                         f32x4 (&acc)[2][2][4][2], G8Frags<T>& f, int ns, bool roll, const GemmArgs& g, int tid, int nm0,
-                                         int nn0) {
-  // ---- even tile ----
-  g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
-  g8_stage(B1o, sB1, k1, wave_lds); g8_wait8_plus(ns);
-  g8_mma<T>(acc[0][0], f.a, f.b0);
-  g8_read_b(B1e, woff, f.b1);
-  g8_stage(A1o, sA1, k1, wave_lds); g8_wait8_plus(ns);
-  if (roll) g8_set_ptrs(g, tid, nm0, nn0, sA0, sA1, sB0, sB1);   // everything staged from here on belongs to the next output tile
-  g8_mma<T>(acc[0][1], f.a, f.b1);
-  g8_read_a(A1e, xoff, f.a);
-  g8_stage(A0e, sA0, k2, wave_lds);
-  g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8_stage(B0e, sB0, k2, wave_lds); g8_wait8_plus(ns);
-  g8_mma<T>(acc[1][0], f.a, f.b0);
-  // ---- odd tile ----
-  g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
-  g8_stage(B1e, sB1, k2, wave_lds); G8_WAIT8();
-  g8_mma<T>(acc[0][0], f.a, f.b0);
-  g8_read_b(B1o, woff, f.b1);
-  g8_stage(A1e, sA1, k2, wave_lds); G8_WAIT8();
-  g8_mma<T>(acc[0][1], f.a, f.b1);
-  g8_read_a(A1o, xoff, f.a);
-  g8_stage(A0o, sA0, k3, wave_lds);
-  g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8_stage(B0o, sB0, k3, wave_lds); G8_WAIT8();
-  g8_mma<T>(acc[1][0], f.a, f.b0);
-}
-
-__device__ __forceinline__ void g8_tile_coords(const GemmArgs& g, int tile, int& tm, int& tn) {
-  constexpr int GC = 4;   // column groups of 4 tiles: see gemm8_kernel
-  const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
-  const int cg = tile / gsz;
-  if (cg < nfull) {
-    const int rem = tile - cg * gsz;
-    tm = rem / GC;
-    tn = cg * GC + rem % GC;
-  } else {
-    const int w = g.tiles_n - nfull * GC, rem = tile - nfull * gsz;
-    tm = rem / w;
-    tn = nfull * GC + rem % w;
-  }
-}
-
-template <typename T, int ACT>
-__global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r = lane & 15, q = lane >> 4;
-
-  // this workgroup's tile list: ids first + per*j inside the contiguous range of its XCD group
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int tq = ntiles >> 3, tr = ntiles & 7;
-  const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  const int first = lo + slot, end = lo + tq + (xcd < tr ? 1 : 0);
-  if (first >= end) return;   // whole workgroup; never taken for ntiles >= gridDim.x
-
-  const int wave_lds = wave * 1024;
-  int xoff[2], woff[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    xoff[kk] = lds_off_x(64 * wm + r, 4 * kk + q);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) woff[kk][nt] = lds_off_w8(32 * wn + g8_w_row(r, nt), 4 * kk + q);
-  }
-  char* const A0e = smem + 0 * G8_SLOT; char* const A1e = smem + 1 * G8_SLOT;
-  char* const B0e = smem + 2 * G8_SLOT; char* const B1e = smem + 3 * G8_SLOT;
-  char* const A0o = smem + 4 * G8_SLOT; char* const A1o = smem + 5 * G8_SLOT;
-  char* const B0o = smem + 6 * G8_SLOT; char* const B1o = smem + 7 * G8_SLOT;
-
-  const int nkt = g.K >> 6;  // even, >= 2
-  int tm, tn;
-  g8_tile_coords(g, first, tm, tn);
-  const char *sA0[2], *sA1[2], *sB0[2], *sB1[2];
-  g8_set_ptrs(g, tid, tm * 256, tn * 256, sA0, sA1, sB0, sB1);
-  // prologue of the first tile (same issue order as the steady state)
-  g8_stage(A0e, sA0, 0, wave_lds); g8_stage(B0e, sB0, 0, wave_lds); g8_stage(B1e, sB1, 0, wave_lds);
-  g8_stage(A1e, sA1, 0, wave_lds); g8_stage(A0o, sA0, 128, wave_lds); g8_stage(B0o, sB0, 128, wave_lds);
-  G8_WAIT8();
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();
-
-  const bool vec8 = gemm_vec8_ok(g);
-  G8Frags<T> f;
-  int ns = 0;   // store instructions this wave issued in the previous tile's epilogue
-  for (int tile = first; tile < end; tile += per) {
-    const int m0 = tm * 256, n0 = tn * 256;
-    int ntm = tm, ntn = tn;
-    const bool has_next = tile + per < end;
-    if (has_next) g8_tile_coords(g, tile + per, ntm, ntn);
-
-    f32x4 acc[2][2][4][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int t = 0; t < nkt; t += 2) {
-      const bool lastpair = t + 2 >= nkt;
-      const bool roll = lastpair && has_next;
-      // K tile t+1 belongs to this output tile (nkt even); t+2 / t+3 roll over into the next tile, or (no next tile)
-      // re-load this tile's last K tile into slots nobody reads again
-      const size_t k1 = (size_t)(t + 1) * 128;
-      const size_t k2 = lastpair ? (roll ? 0 : (size_t)(nkt - 1) * 128) : (size_t)(t + 2) * 128;
-      const size_t k3 = lastpair ? (roll ? 128 : (size_t)(nkt - 1) * 128) : (size_t)(t + 3) * 128;
-      g8q_iter<T>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, sA0, sA1, sB0, sB1, k1, k2, k3, wave_lds, xoff, woff, acc, f,
-                  t == 0 ? ns : 0, roll, g, tid, ntm * 256, ntn * 256);
-    }
-
-    // epilogue of this tile; the next tile's first K tiles are already in flight
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int row = m0 + 128 * mh + 64 * wm + 16 * mt + r;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-          float v[8];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mh][nh][mt][nt][j];
-          gemm_epilogue_row<T, ACT, 8>(g, row, n0 + 128 * nh + 32 * wn + 8 * q, v, vec8);
-        }
-      }
-    {  // exact count of the store instructions this wave just executed (a store runs if any lane has work)
-      int rows_on = 0, segs_on = 0;
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) rows_on += (m0 + 128 * mh + 64 * wm + 16 * mt) < g.M;
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        const int cb = n0 + 128 * nh + 32 * wn;
-        if (!g.out_f32 && vec8) segs_on += cb < g.N;
-        else segs_on += (cb < g.N) + (cb + 4 < g.N);
-      }
-      ns = __builtin_amdgcn_readfirstlane(rows_on * segs_on);
-    }
-    tm = ntm; tn = ntn;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-}
-
-template <typename T, int ACT>
-static int g8p_launch(GemmArgs& g, hipStream_t stream) {
-  auto kern = gemm8p_kernel<T, ACT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  g.tiles_m = (g.M + 255) / 256;
-  g.tiles_n = (g.N + 255) / 256;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int grid = ntiles >= 256 ? 256 : (ntiles / 8) * 8;   // multiple of 8: one slot list per XCD group
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 8 * G8_SLOT, stream, g);
-  VMC_CHECK_LAUNCH();
-  return 0;
-}
-
 template <typename T, int ACT>
 static int g8_launch(GemmArgs& g, hipStream_t stream) {
   auto kern = gemm8_kernel<T, ACT>;
@@ -527,17 +329,6 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
 
 template <typename T>
 static int g8_act(GemmArgs& g, int act, hipStream_t s) {
-  // persistent kernel unless an operand does not fit a 2 GiB buffer descriptor (VMC_GEMM8=1 forces the
-  // one-tile-per-workgroup kernel for A/B measurements)
-  if (vmc_gemm_variant() == 2) {
-    switch (act) {
-      case VMC_ACT_NONE: return g8p_launch<T, VMC_ACT_NONE>(g, s);
-      case VMC_ACT_QUICKGELU: return g8p_launch<T, VMC_ACT_QUICKGELU>(g, s);
-      case VMC_ACT_GELU_ERF: return g8p_launch<T, VMC_ACT_GELU_ERF>(g, s);
-      case VMC_ACT_RELU: return g8p_launch<T, VMC_ACT_RELU>(g, s);
-    }
-    return VMC_E_ARG;
-  }
   switch (act) {
     case VMC_ACT_NONE: return g8_launch<T, VMC_ACT_NONE>(g, s);
     case VMC_ACT_QUICKGELU: return g8_launch<T, VMC_ACT_QUICKGELU>(g, s);

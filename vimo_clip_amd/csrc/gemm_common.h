@@ -16,6 +16,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   char* zout;     // optional 16-bit side output [M, ldz]: the value before the activation (bias included) -- what the backward of
   int ldz;        // act(x W^T + b) needs, written by the same epilogue instead of a second pass (vmc_linear_preact)
+  int variant;    // VMC_GEMM_* of include/vmc.h (per call; the library keeps no state)
   int k_slices;   // > 1: split-K (gemm_kernel only): blockIdx.y owns a K range and atomically adds into the f32 output
 };
 
@@ -75,9 +76,6 @@ __device__ __forceinline__ bool gemm_vec8_ok(const GemmArgs& g) {
   return ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.res == nullptr || (g.ldres & 7) == 0);
 }
 
-// Large-GEMM kernel selection (vmc_set_gemm_variant): 0 two-stage tiles only, 1 8-phase one tile per workgroup,
-// 2 8-phase persistent.  Initialised from the environment variable VMC_GEMM8, default in gemm.hip.
-int vmc_gemm_variant();
 
 // 8-phase 256x256 kernel family (gemm8.hip); returns VMC_E_SHAPE when the shape does not qualify.
 int vmc_gemm8_launch(GemmArgs& g, int act, int dtype16, hipStream_t stream);

@@ -1,0 +1,913 @@
+// Fused TFAM forward chain for short clips (gfx950): the small-batch, weight-streaming regime of
+// TFAM/models/AMO_CLIP.py:37-51 (AttentionLayer.forward), :84,:170 (mean-pool + classifier).
+//
+// At the reference batch (8 clips x 16 tokens = 128 token rows) a layer is ~15 MB of 16-bit weights against
+// 0.25 GFLOP: every linear is a skinny GEMM whose only cost is getting its weight rows onto the chip once and
+// its 128..256 activation rows into every workgroup.  The chain below is what is left after removing everything
+// that is not a true all-to-all dependency (cdna_hip_programming.md 5.6: "cut at every all-to-all seam"):
+//
+//   kv     K|V of ALL layers' cross attention = motion tokens x [L*2D, D]^T      (hoisted: AMO_CLIP.py:43-45
+//          projects the same raw motion tokens in every layer)
+//   per layer (6 launches; the three post-norm LayerNorms, the two attentions, the bias / ReLU / residual adds
+//   and the fp32 -> 16-bit casts all live in prologues / epilogues):
+//     1  qkv  = LN_prev(y) Wqkv^T + b            prologue LayerNorm (layer 0: the raw fp32 tokens), side output x = LN_prev(y)
+//     2  y    = x + softmax(q k^T) v Wo^T + b    prologue: masked self attention of the block's clips, written straight
+//                                                into the LDS image of the GEMM's A operand
+//     3  q    = LN_self(y) Wq^T + b              side output x1 = LN_self(y)
+//     4  y    = x1 + attn(q, K_l, V_l) Wo^T + b  cross attention against the hoisted K|V
+//     5  h    = relu(LN_cross(y) W1^T + b)       side output x2 = LN_cross(y)
+//     6  y    = x2 + h W2^T + b                  K = dim_feedforward: LDS-DMA ring over K chunks
+//   pool   16-bit LN_cls(mean_t LN_ffn(y))       mean over ALL T rows, padded ones included (AMO_CLIP.py:170)
+//   head   GELU_erf(. W^T + b), then the class logits (fp32)
+//
+// Geometry of one GEMM workgroup: 256 threads, 32 token rows x BN (16/32/64) output columns, the full K (<= 768 ... 1024)
+// of both operands resident in LDS: W rows arrive by LDS-DMA (global_load_lds_dwordx4, full 128-B lines, XOR-16
+// swizzle applied on the per-lane SOURCE address), A rows go through registers because they are transformed on the
+// way (LayerNorm / cast / attention).  Waves split the tile 2 (row tiles of 16) x 2 (K halves); the two K halves are
+// summed through LDS.  MFMA operands are passed as (W, X) so a lane owns 4 consecutive output columns of one row.
+// Workgroups that share a W tile are given block ids that agree mod 8 (same XCD, same L2).
+//
+// Supported: T, Tk <= 32, d_model in {512, 768}, head_dim in {64, 96}, (clips per block) * nhead a multiple of 4.
+// Everything else returns VMC_E_SHAPE and the caller uses the general per-op path.
+#include "common.h"
+
+namespace {
+
+constexpr int TF_BM = 32;
+constexpr int TF_NTH = 256;
+
+enum { PRO_F32 = 0, PRO_LN = 1, PRO_16 = 2, PRO_ATTN = 3 };
+enum { EPI_ACT16 = 0, EPI_RESID32 = 1, EPI_BIAS32 = 2 };
+
+struct TfArgs {
+  const void* A;            // PRO_F32 / PRO_LN: float [M, lda]; PRO_16: 16-bit [M, lda]
+  int lda;
+  const float* ln_g;        // PRO_LN
+  const float* ln_b;
+  float eps;
+  float* xout;              // PRO_LN, optional: LN(A) as fp32 [M, K] (residual operand of a later launch)
+  const uint16_t* q;        // PRO_ATTN: q [B*T, ldq], k / v [B*Tk, ldk / ldv] (head h at columns h*DH..)
+  const uint16_t* k;
+  const uint16_t* v;
+  int ldq, ldk, ldv;
+  const uint8_t* kmask;     // [B, Tk], 1 = attend; may be null
+  int T, Tk, H, B, cpb;     // cpb: clips per row block
+  float scale;
+  const uint16_t* W;        // [N, K] 16-bit, row stride ldw
+  int ldw;
+  const float* bias;
+  const float* resid;       // EPI_RESID32: fp32 [M, ldres]
+  int ldres;
+  void* out;
+  int ldo;
+  int M, N, K;
+  int rpb;                  // token rows per row block (<= 32)
+  int n_tiles, n_rb;
+  int act;
+};
+
+__device__ __forceinline__ int swz16(int chunk, int row) { return chunk ^ (row & 15); }
+
+// (n tile, row block) of a block id: blocks that share a W tile agree mod 8 -> same XCD (round-robin dispatch).
+__device__ __forceinline__ void tf_block_map(int bid, int n_tiles, int n_rb, int& nt, int& rb) {
+  const int n8 = n_tiles & ~7;
+  if (bid < n8 * n_rb) {
+    const int g = bid >> 3;
+    rb = g % n_rb;
+    nt = (g / n_rb) * 8 + (bid & 7);
+  } else {
+    const int rem = bid - n8 * n_rb, tail = n_tiles - n8;
+    nt = n8 + rem % tail;
+    rb = rem / tail;
+  }
+}
+
+// W tile [BN rows x K] -> LDS image by LDS-DMA; image chunk p = (row, phys) holds logical chunk phys ^ (row & 15).
+__device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0, int BN, int wave, int lane) {
+  const int cpr = a.K >> 3;                    // 16-B chunks per row
+  const int total = (BN * cpr) >> 6;           // wave instructions (64 chunks each)
+  for (int ii = wave; ii < total; ii += 4) {
+    const int p = ii * 64 + lane;
+    const int row = p / cpr, phys = p - row * cpr;
+    const int nrow = min(n0 + row, a.N - 1);   // rows past N (odd head widths) re-read the last row; never stored
+    const uint16_t* src = a.W + (size_t)nrow * a.ldw + (swz16(phys, row) << 3);
+    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(w_img + ii * 1024), 16, 0, 0);
+  }
+}
+
+// ---- A operand producers --------------------------------------------------------------------------------------------
+// thread t: row t>>3, 8 threads per row, float4 at columns 4*(t8 + 8 i).
+template <typename T, int KD, int BN>
+__device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, int nt, int tid) {
+  constexpr int NI = KD / 32;
+  const int row = tid >> 3, t8 = tid & 7;
+  const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
+  const float* src = (const float*)a.A + (size_t)grow * a.lda;
+  float4 x[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) x[i] = *(const float4*)(src + 4 * (t8 + 8 * i));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  const float mean = s * (1.0f / KD);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+    v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+  }
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  const float rstd = rsqrtf(v * (1.0f / KD) + a.eps);
+  const bool emit = a.xout != nullptr && row < a.rpb && rb * a.rpb + row < a.M;
+  float* xo = a.xout + (size_t)grow * KD;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c4 = t8 + 8 * i;
+    const float4 g = *(const float4*)(a.ln_g + 4 * c4), b = *(const float4*)(a.ln_b + 4 * c4);
+    float4 y;
+    y.x = x[i].x * rstd * g.x + b.x; y.y = x[i].y * rstd * g.y + b.y;
+    y.z = x[i].z * rstd * g.z + b.z; y.w = x[i].w * rstd * g.w + b.w;
+    if (emit && (4 * c4) / BN == nt) *(float4*)(xo + 4 * c4) = y;  // this block's BN columns of the fp32 side output
+    *(uint2*)(a_img + row * (KD * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
+        make_uint2(pack2<T>(y.x, y.y), pack2<T>(y.z, y.w));
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void tf_pro_f32(const TfArgs& a, char* a_img, int rb, int tid) {
+  const int row = tid >> 3, t8 = tid & 7;
+  const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
+  const float* src = (const float*)a.A + (size_t)grow * a.lda;
+  const int ni = a.K >> 5;
+  for (int i0 = 0; i0 < ni; i0 += 8) {
+    float4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i0 + i < ni) x[i] = *(const float4*)(src + 4 * (t8 + 8 * (i0 + i)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i0 + i < ni) {
+        const int c4 = t8 + 8 * (i0 + i);
+        *(uint2*)(a_img + row * (a.K * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
+            make_uint2(pack2<T>(x[i].x, x[i].y), pack2<T>(x[i].z, x[i].w));
+      }
+  }
+}
+
+// 16-bit A rows by LDS-DMA (same image as W)
+__device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, int wave, int lane) {
+  const int cpr = a.K >> 3;
+  const int total = (TF_BM * cpr) >> 6;
+  for (int ii = wave; ii < total; ii += 4) {
+    const int p = ii * 64 + lane;
+    const int row = p / cpr, phys = p - row * cpr;
+    const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
+    const uint16_t* src = (const uint16_t*)a.A + (size_t)grow * a.lda + (swz16(phys, row) << 3);
+    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(a_img + ii * 1024), 16, 0, 0);
+  }
+}
+
+// V rows of the block's clips -> LDS image [(cpb-1)*Tk + 32 rows][D] by LDS-DMA (rows past the data repeat the last key:
+// finite values under a zero probability).
+__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int wave, int lane) {
+  const int cpr = a.K >> 3;
+  const int vrows = (a.cpb - 1) * a.Tk + 32;
+  const int total = (vrows * cpr + 63) >> 6;
+  const int c0 = rb * a.cpb;
+  for (int ii = wave; ii < total; ii += 4) {
+    const int p = min(ii * 64 + lane, vrows * cpr - 1);
+    const int row = p / cpr, phys = p - row * cpr;
+    const int ci = min(row / a.Tk, a.cpb - 1);
+    const int key = min(row - ci * a.Tk, a.Tk - 1);
+    const int clip = min(c0 + ci, a.B - 1);
+    const uint16_t* src = a.v + ((size_t)clip * a.Tk + key) * a.ldv + (swz16(phys, row) << 3);
+    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(v_img + ii * 1024), 16, 0, 0);
+  }
+}
+
+// Masked attention of the block's (clip, head) pairs; one wave per pair, PB pairs in flight per wave.  S^T = K Q^T with the
+// K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
+// of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
+// operand of the out_proj GEMM.
+template <typename T, int DH, int QT>
+__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, char* a_img, const char* v_img, int rb, int wave, int lane) {
+  constexpr int KK = DH / 32, DT = DH / 16, PB = 4 / QT;
+  const int r = lane & 15, q = lane >> 4;
+  const int c0 = rb * a.cpb;
+  const int npairs = a.cpb * a.H;
+  const int rowb = a.K * 2;
+  const float c2 = a.scale * 1.4426950408889634f;
+  const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
+  // key liveness of this lane's keys (16 nt + 4 q + j) per clip of the block
+  uint32_t livebits[2] = {0u, 0u};
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int clip = min(c0 + min(ci, a.cpb - 1), a.B - 1);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = 16 * nt + 4 * q + j;
+        bool live = key < a.Tk;
+        if (live && a.kmask != nullptr) live = a.kmask[(size_t)clip * a.Tk + key] != 0;
+        livebits[ci] |= (live ? 1u : 0u) << (4 * nt + j);
+      }
+  }
+  for (int p0 = wave * PB; p0 < npairs; p0 += 4 * PB) {
+    uint4 kf[PB][2][KK], qf[PB][QT][KK];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int p = min(p0 + i, npairs - 1);
+      const int ci = p / a.H, h = p - ci * a.H;
+      const int clip = min(c0 + ci, a.B - 1);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const uint16_t* kr = a.k + ((size_t)clip * a.Tk + min(16 * nt + r, a.Tk - 1)) * a.ldk + h * DH + 8 * q;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[i][nt][kk] = *(const uint4*)(kr + 32 * kk);
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const uint16_t* qr = a.q + ((size_t)clip * a.T + min(16 * qt + r, a.T - 1)) * a.ldq + h * DH + 8 * q;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[i][qt][kk] = *(const uint4*)(qr + 32 * kk);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      if (p0 + i >= npairs) break;                 // wave-uniform
+      const int p = p0 + i;
+      const int ci = p / a.H, h = p - ci * a.H;
+      const uint32_t lb = ci ? livebits[1] : livebits[0];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 s[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) s[nt] = T::mfma16(kf[i][nt][kk], qf[i][qt][kk], s[nt]);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!((lb >> (4 * nt + j)) & 1u)) s[nt][j] = -INFINITY;
+            m = fmaxf(m, s[nt][j]);
+          }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mc = m * c2;                  // a fully masked row gives exp2(NaN): NaN output, as torch
+        uint4 pf;
+        pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][1], c2, -mc)));
+        pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][3], c2, -mc)));
+        pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][1], c2, -mc)));
+        pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][3], c2, -mc)));
+        f32x4 osum = T::mfma16(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        f32x4 o[DT];
+        // transposed 4-key x 16-column blocks: this lane supplies key row 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
+        const int vrow0 = ci * a.Tk + 4 * q + (r >> 2);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int col = h * DH + 16 * dt + 4 * (r & 3);
+          const char* p0a = v_img + vrow0 * rowb + (swz16(col >> 3, vrow0) << 4) + (((col >> 2) & 1) << 3);
+          const char* p1a = v_img + (vrow0 + 16) * rowb + (swz16(col >> 3, vrow0 + 16) << 4) + (((col >> 2) & 1) << 3);
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0a);
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a);
+          const uint2 x0 = __builtin_bit_cast(uint2, v0), x1 = __builtin_bit_cast(uint2, v1);
+          o[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+        const float inv = 1.0f / osum[0];
+        const int arow = ci * a.T + 16 * qt + r;   // row of the A image
+        if (16 * qt + r < a.T) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int col = h * DH + 16 * dt + 4 * q;
+            *(uint2*)(a_img + arow * rowb + (swz16(col >> 3, arow) << 4) + (((col >> 2) & 1) << 3)) =
+                make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
+          }
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t tf_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(const VMC_LDS char*)p; }
+
+// ---- epilogue: one lane's 4 consecutive columns of one row -------------------------------------------------------------
+template <typename T, int EPI>
+__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v) {
+  if (col >= a.N) return;
+  if (col + 3 < a.N) {
+    const float4 b = *(const float4*)(a.bias + col);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    if (EPI == EPI_RESID32) {
+      const float4 rr = *(const float4*)(a.resid + (size_t)grow * a.ldres + col);
+      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    }
+    if (EPI == EPI_ACT16) {
+      *(uint2*)((uint16_t*)a.out + (size_t)grow * a.ldo + col) =
+          make_uint2(pack2<T>(apply_act_rt(v[0], a.act), apply_act_rt(v[1], a.act)),
+                     pack2<T>(apply_act_rt(v[2], a.act), apply_act_rt(v[3], a.act)));
+    } else if ((a.ldo & 3) == 0) {
+      *(float4*)((float*)a.out + (size_t)grow * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ((float*)a.out)[(size_t)grow * a.ldo + col + j] = v[j];
+    }
+  } else {                                       // ragged last columns (class count not a multiple of 4)
+    for (int j = 0; j < 4 && col + j < a.N; ++j) {
+      float x = v[j] + a.bias[col + j];
+      if (EPI == EPI_RESID32) x += a.resid[(size_t)grow * a.ldres + col + j];
+      if (EPI == EPI_ACT16) ((uint16_t*)a.out)[(size_t)grow * a.ldo + col + j] = T::from_f32(apply_act_rt(x, a.act));
+      else ((float*)a.out)[(size_t)grow * a.ldo + col + j] = x;
+    }
+  }
+}
+
+// ---- single-shot K kernel ----------------------------------------------------------------------------------------------
+// LDS: [A image 32 x K][W image BN x K][k-half exchange 2 x NTN x 1 KiB][V image (PRO_ATTN)]
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT>
+__global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
+  constexpr int NTN = BN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int nt, rb;
+  tf_block_map(blockIdx.x, a.n_tiles, a.n_rb, nt, rb);
+  const int rowb = a.K * 2;
+  char* a_img = tf_smem;
+  char* w_img = a_img + TF_BM * rowb;
+  char* red = w_img + BN * rowb;
+  char* v_img = red + 2 * NTN * 1024;
+  const int n0 = nt * BN;
+
+  tf_stage_w(a, w_img, n0, BN, wave, lane);
+  if constexpr (PRO == PRO_ATTN) tf_stage_v(a, v_img, rb, wave, lane);
+  if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane);
+  if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN>(a, a_img, rb, nt, tid);
+  if constexpr (PRO == PRO_F32) tf_pro_f32<T>(a, a_img, rb, tid);
+  if constexpr (PRO == PRO_ATTN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                             // V (and W) images complete
+    tf_pro_attn<T, DH, QT>(a, a_img, v_img, rb, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave & 1, ks = wave >> 1;
+  const int ksteps = a.K >> 6;                   // 32-wide k-steps per K half
+  f32x4 acc[NTN];
+#pragma unroll
+  for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int arow = 16 * rt + r;
+  const char* ap = a_img + arow * rowb;
+  for (int kk = 0; kk < ksteps; ++kk) {
+    const int chunk = (ks * ksteps + kk) * 4 + q;
+    const uint4 af = *(const uint4*)(ap + (swz16(chunk, arow) << 4));
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) {
+      const int wrow = 16 * n + r;
+      const uint4 wf = *(const uint4*)(w_img + wrow * rowb + (swz16(chunk, wrow) << 4));
+      acc[n] = T::mfma16(wf, af, acc[n]);
+    }
+  }
+  if (ks == 1) {
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16) = acc[n];
+  }
+  __syncthreads();
+  if (ks == 0) {
+    const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
+    if (lrow < a.rpb && grow < a.M) {
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) {
+        const f32x4 o = *(const f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16);
+        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o);
+      }
+    }
+  }
+}
+
+// ---- chunked-K kernel (FFN second linear): A 16-bit and W both by LDS-DMA through an NST-deep ring -----------------------
+template <int N>
+__device__ __forceinline__ void tf_wait_vm() {
+  if (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN, int KC, int NST>
+__global__ void __launch_bounds__(TF_NTH) tf_gemm_ring_kernel(const TfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
+  constexpr int NTN = BN / 16;
+  constexpr int CPR = KC / 8;                          // 16-B chunks per image row
+  constexpr int A_INSTR = TF_BM * CPR / 64 / 4;        // LDS-DMA instructions per wave per chunk
+  constexpr int W_INSTR = (BN * CPR / 64 + 3) / 4;
+  constexpr int PER = A_INSTR + W_INSTR;
+  constexpr int STAGE = (TF_BM + BN) * KC * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int nt, rb;
+  tf_block_map(blockIdx.x, a.n_tiles, a.n_rb, nt, rb);
+  const int n0 = nt * BN;
+  const int nchunks = a.K / KC;
+  char* red = tf_smem + NST * STAGE;
+
+  auto stage = [&](int c) {
+    char* base = tf_smem + (c % NST) * STAGE;
+    const size_t koff = (size_t)c * KC;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int ii = wave + 4 * i;
+      const int p = ii * 64 + lane, row = p / CPR, phys = p - row * CPR;
+      const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
+      const uint16_t* src = (const uint16_t*)a.A + (size_t)grow * a.lda + koff + (swz16(phys, row) << 3);
+      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(base + ii * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i) {
+      const int ii = min(wave + 4 * i, BN * CPR / 64 - 1);     // surplus instructions of a wave re-stage the last piece
+      const int p = ii * 64 + lane, row = p / CPR, phys = p - row * CPR;
+      const uint16_t* src = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + koff + (swz16(phys, row) << 3);
+      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(base + TF_BM * KC * 2 + ii * 1024), 16, 0, 0);
+    }
+  };
+
+  const int r = lane & 15, q = lane >> 4;
+  const int rt = wave & 1, ks = wave >> 1;
+  f32x4 acc[NTN];
+#pragma unroll
+  for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NST - 1; ++c)
+    if (c < nchunks) stage(c);
+  const int arow = 16 * rt + r;
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + NST - 1 < nchunks) {
+      stage(c + NST - 1);
+      tf_wait_vm<(NST - 1) * PER>();             // everything but the NST-1 youngest chunks has landed: chunk c is in
+    } else {
+      tf_wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* a_img = tf_smem + (c % NST) * STAGE;
+    const char* w_img = a_img + TF_BM * KC * 2;
+    uint4 af[KC / 64], wf[NTN][KC / 64];
+#pragma unroll
+    for (int kk = 0; kk < KC / 64; ++kk) {
+      const int chunk = (ks * (KC / 64) + kk) * 4 + q;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(af[kk]) : "v"(tf_lds_addr(a_img + arow * (KC * 2) + (swz16(chunk, arow) << 4))) : "memory");
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) {
+        const int wrow = 16 * n + r;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[n][kk]) : "v"(tf_lds_addr(w_img + wrow * (KC * 2) + (swz16(chunk, wrow) << 4))) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KC / 64; ++kk)
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) acc[n] = T::mfma16(wf[n][kk], af[kk], acc[n]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                // ring slot c % NST may be restaged by the next iteration
+  }
+  if (ks == 1) {
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16) = acc[n];
+  }
+  __syncthreads();
+  if (ks == 0) {
+    const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
+    if (lrow < a.rpb && grow < a.M) {
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) {
+        const f32x4 o = *(const f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16);
+        tf_epilogue<T, EPI_RESID32>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o);
+      }
+    }
+  }
+}
+
+// ---- mean-pool + the two LayerNorms of the tail: pooled16[b] = LN_cls(mean_t LN_ffn(y[b, t])) ------------------------------
+template <typename T, int D>
+__global__ void __launch_bounds__(256) tf_pool_kernel(const float* __restrict__ y, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                      const float* __restrict__ g2, const float* __restrict__ b2,
+                                                      uint16_t* __restrict__ out, int Tn, float eps) {
+  constexpr int NI = D / 256;                    // float4 per lane per row
+  __shared__ float part[4][D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  float4 accp[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) accp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = wave; t < Tn; t += 4) {
+    const float* row = y + ((size_t)b * Tn + t) * D;
+    float4 x[NI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      x[i] = *(const float4*)(row + 4 * (lane + 64 * i));
+      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+      v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float4 g = *(const float4*)(g1 + 4 * (lane + 64 * i)), bb = *(const float4*)(b1 + 4 * (lane + 64 * i));
+      accp[i].x += x[i].x * rstd * g.x + bb.x; accp[i].y += x[i].y * rstd * g.y + bb.y;
+      accp[i].z += x[i].z * rstd * g.z + bb.z; accp[i].w += x[i].w * rstd * g.w + bb.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) *(float4*)(&part[wave][4 * (lane + 64 * i)]) = accp[i];
+  __syncthreads();
+  if (wave == 0) {
+    float4 x[NI];
+    float s = 0.f;
+    const float invT = 1.0f / Tn;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      const float4 p0 = *(const float4*)(&part[0][c]), p1 = *(const float4*)(&part[1][c]), p2 = *(const float4*)(&part[2][c]),
+                   p3 = *(const float4*)(&part[3][c]);
+      x[i].x = ((p0.x + p1.x) + (p2.x + p3.x)) * invT; x[i].y = ((p0.y + p1.y) + (p2.y + p3.y)) * invT;
+      x[i].z = ((p0.z + p1.z) + (p2.z + p3.z)) * invT; x[i].w = ((p0.w + p1.w) + (p2.w + p3.w)) * invT;
+      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+      v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+    }
+    const float rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      const float4 g = *(const float4*)(g2 + c), bb = *(const float4*)(b2 + c);
+      *(uint2*)(out + (size_t)b * D + c) = make_uint2(pack2<T>(x[i].x * rstd * g.x + bb.x, x[i].y * rstd * g.y + bb.y),
+                                                      pack2<T>(x[i].z * rstd * g.z + bb.z, x[i].w * rstd * g.w + bb.w));
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+constexpr size_t TF_LDS_MAX = 160 * 1024;
+
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT>
+int tf_launch(TfArgs& a, hipStream_t s) {
+  const size_t rowb = (size_t)a.K * 2;
+  size_t lds = TF_BM * rowb + BN * rowb + 2 * (BN / 16) * 1024;
+  if (PRO == PRO_ATTN) lds += (size_t)((a.cpb - 1) * a.Tk + 32) * rowb + 1024;   // + one LDS-DMA piece of slack
+  if (lds > TF_LDS_MAX) return VMC_E_SHAPE;
+  a.n_tiles = (a.N + BN - 1) / BN;
+  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
+  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT>;
+  static bool attr_done = false;                // per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TF_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int BN, int KC, int NST>
+int tf_launch_ring(TfArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)NST * (TF_BM + BN) * KC * 2 + 2 * (BN / 16) * 1024;
+  if (lds > TF_LDS_MAX || a.K % KC) return VMC_E_SHAPE;
+  a.n_tiles = (a.N + BN - 1) / BN;
+  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
+  auto kern = tf_gemm_ring_kernel<T, BN, KC, NST>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TF_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// output-column tile by row count: 16 columns while the launch is latency bound, wider tiles once the A rows re-read by
+// every column tile dominate the on-chip traffic
+inline int tf_pick_bn(int M, int N) {
+  if (N % 64 == 0 && M > 512) return 64;
+  if (N % 32 == 0 && M > 192) return 32;
+  return 16;
+}
+
+template <typename T, int PRO, int EPI, int KD>
+int tf_dispatch_bn(TfArgs& a, int bn, hipStream_t s) {
+  if (bn == 64) return tf_launch<T, 64, PRO, EPI, KD, 64, 1>(a, s);
+  if (bn == 32) return tf_launch<T, 32, PRO, EPI, KD, 64, 1>(a, s);
+  return tf_launch<T, 16, PRO, EPI, KD, 64, 1>(a, s);
+}
+
+template <typename T>
+int tf_dispatch_attn(TfArgs& a, int bn, int dh, hipStream_t s) {
+  const int qt = a.T > 16 ? 2 : 1;
+#define TF_ATTN(BNV, DHV, QTV) return tf_launch<T, BNV, PRO_ATTN, EPI_RESID32, 0, DHV, QTV>(a, s)
+  if (bn == 32) {
+    if (dh == 64 && qt == 1) TF_ATTN(32, 64, 1);
+    if (dh == 64) TF_ATTN(32, 64, 2);
+    if (dh == 96 && qt == 1) TF_ATTN(32, 96, 1);
+    if (dh == 96) TF_ATTN(32, 96, 2);
+  } else {
+    if (dh == 64 && qt == 1) TF_ATTN(16, 64, 1);
+    if (dh == 64) TF_ATTN(16, 64, 2);
+    if (dh == 96 && qt == 1) TF_ATTN(16, 96, 1);
+    if (dh == 96) TF_ATTN(16, 96, 2);
+  }
+#undef TF_ATTN
+  return VMC_E_SHAPE;
+}
+
+struct TfDims {
+  int B, T, Tk, D, H, ff, L, C, has_cross;
+};
+
+inline int tf_check(const TfDims& d) {
+  if (d.B <= 0 || d.T <= 0 || d.T > 32 || d.L <= 0 || d.C <= 0) return VMC_E_SHAPE;
+  if (d.D != 512 && d.D != 768) return VMC_E_SHAPE;
+  if (d.H <= 0 || d.D % d.H) return VMC_E_SHAPE;
+  const int dh = d.D / d.H;
+  if (dh != 64 && dh != 96) return VMC_E_SHAPE;
+  if (d.ff % 512 || d.ff <= 0) return VMC_E_SHAPE;
+  if (d.has_cross && (d.Tk <= 0 || d.Tk > 32)) return VMC_E_SHAPE;
+  const int cpb = d.T <= 16 ? 2 : 1;
+  if ((cpb * d.H) % 4) return VMC_E_SHAPE;
+  return 0;
+}
+
+}  // namespace
+
+// ---- pack layout ---------------------------------------------------------------------------------------------------------
+// 16-bit weight pack: per layer [self_in 3D x D | self_out D x D | cross_q D x D | cross_out D x D | ffn0 ff x D | ffn3 D x ff],
+// then [kv_all (L*2D) x D | cls1 (D/2) x D | cls4 C x (D/2)].  kv_all rows l*2D..: rows D:3D of layer l's cross in_proj.
+// fp32 parameter pack: per layer [b_self_in 3D | b_self_out D | b_cross_q D | b_cross_out D | b_ffn0 ff | b_ffn3 D |
+// norm_self g,b | norm_cross g,b | norm_ffn g,b], then [b_kv_all L*2D | cls_ln g,b | b_cls1 D/2 | b_cls4 C].
+static size_t tf_w_layer(int D, int ff) { return (size_t)6 * D * D + (size_t)2 * ff * D; }
+static size_t tf_p_layer(int D, int ff) { return (size_t)3 * D + 4 * (size_t)D + ff + 6 * (size_t)D; }   // 3D + D + D + D + ff + D + 3 x 2D
+
+extern "C" long long vmc_tfam_pack_offset(int slot, int layer, int D, int ff, int L, int C) {
+  (void)C;
+  const size_t wl = tf_w_layer(D, ff), pl = tf_p_layer(D, ff);
+  const size_t DD = (size_t)D * D;
+  switch (slot) {
+    case VMC_TFAM_W_SELF_IN: return (long long)(layer * wl);
+    case VMC_TFAM_W_SELF_OUT: return (long long)(layer * wl + 3 * DD);
+    case VMC_TFAM_W_CROSS_Q: return (long long)(layer * wl + 4 * DD);
+    case VMC_TFAM_W_CROSS_OUT: return (long long)(layer * wl + 5 * DD);
+    case VMC_TFAM_W_FFN0: return (long long)(layer * wl + 6 * DD);
+    case VMC_TFAM_W_FFN3: return (long long)(layer * wl + 6 * DD + (size_t)ff * D);
+    case VMC_TFAM_W_KV_ALL: return (long long)(L * wl + (size_t)layer * 2 * DD);
+    case VMC_TFAM_W_CLS1: return (long long)(L * wl + (size_t)L * 2 * DD);
+    case VMC_TFAM_W_CLS4: return (long long)(L * wl + (size_t)L * 2 * DD + (size_t)(D / 2) * D);
+    case VMC_TFAM_W_END: return (long long)(L * wl + (size_t)L * 2 * DD + (size_t)(D / 2) * D + (size_t)C * (D / 2));
+    case VMC_TFAM_P_SELF_IN_B: return (long long)(layer * pl);
+    case VMC_TFAM_P_SELF_OUT_B: return (long long)(layer * pl + 3 * D);
+    case VMC_TFAM_P_CROSS_Q_B: return (long long)(layer * pl + 4 * D);
+    case VMC_TFAM_P_CROSS_OUT_B: return (long long)(layer * pl + 5 * D);
+    case VMC_TFAM_P_FFN0_B: return (long long)(layer * pl + 6 * D);
+    case VMC_TFAM_P_FFN3_B: return (long long)(layer * pl + 6 * D + ff);
+    case VMC_TFAM_P_NORM_SELF: return (long long)(layer * pl + 7 * D + ff);        // gamma, then beta at +D
+    case VMC_TFAM_P_NORM_CROSS: return (long long)(layer * pl + 9 * D + ff);
+    case VMC_TFAM_P_NORM_FFN: return (long long)(layer * pl + 11 * D + ff);
+    case VMC_TFAM_P_KV_ALL_B: return (long long)(L * pl + (size_t)layer * 2 * D);
+    case VMC_TFAM_P_CLS_LN: return (long long)(L * pl + (size_t)L * 2 * D);
+    case VMC_TFAM_P_CLS1_B: return (long long)(L * pl + (size_t)L * 2 * D + 2 * D);
+    case VMC_TFAM_P_CLS4_B: return (long long)(L * pl + (size_t)L * 2 * D + 2 * D + D / 2);
+    case VMC_TFAM_P_END: return (long long)(L * pl + (size_t)L * 2 * D + 2 * D + D / 2 + ((C + 3) & ~3));
+    default: return -1;
+  }
+}
+
+// workspace: [y f32 M*D][xa f32 M*D][xb f32 M*D][qkv16 M*3D][q16 M*D][h16 M*ff][kv16 Mk*L*2D][pool16 B*D][g16 B*D/2]
+namespace {
+struct TfWs {
+  float *y, *xa, *xb;
+  uint16_t *qkv, *q, *h, *kv, *pool, *g;
+  size_t bytes;
+};
+inline TfWs tf_ws(void* base, const TfDims& d) {
+  const size_t M = (size_t)d.B * d.T, Mk = (size_t)d.B * (d.has_cross ? d.Tk : 0);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* p = (char*)base;
+  TfWs w;
+  size_t o = 0;
+  w.y = (float*)(p + o); o += al(M * d.D * 4);
+  w.xa = (float*)(p + o); o += al(M * d.D * 4);
+  w.xb = (float*)(p + o); o += al(M * d.D * 4);
+  w.qkv = (uint16_t*)(p + o); o += al(M * 3 * d.D * 2);
+  w.q = (uint16_t*)(p + o); o += al(M * d.D * 2);
+  w.h = (uint16_t*)(p + o); o += al(M * d.ff * 2);
+  w.kv = (uint16_t*)(p + o); o += al(Mk * d.L * 2 * d.D * 2);
+  w.pool = (uint16_t*)(p + o); o += al((size_t)d.B * d.D * 2);
+  w.g = (uint16_t*)(p + o); o += al((size_t)d.B * (d.D / 2) * 2);
+  w.bytes = o;
+  return w;
+}
+
+template <typename T, int PRO, int EPI>
+int tf_gemm_kd(TfArgs& a, int bn, int D, hipStream_t s) {
+  if constexpr (PRO != PRO_LN) {
+    return tf_dispatch_bn<T, PRO, EPI, 0>(a, bn, s);
+  } else {
+    if (D == 768) return tf_dispatch_bn<T, PRO, EPI, 768>(a, bn, s);
+    return tf_dispatch_bn<T, PRO, EPI, 512>(a, bn, s);
+  }
+}
+
+template <typename T>
+int tf_kv_impl(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w, hipStream_t s) {
+  TfArgs a = {};
+  a.A = motion; a.lda = d.D;
+  a.M = d.B * d.Tk; a.N = d.L * 2 * d.D; a.K = d.D; a.rpb = 32;
+  a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_KV_ALL, 0, d.D, d.ff, d.L, d.C); a.ldw = d.D;
+  a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, 0, d.D, d.ff, d.L, d.C);
+  a.out = w.kv; a.ldo = a.N; a.act = VMC_ACT_NONE;
+  return tf_gemm_kd<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N), d.D, s);
+}
+
+// one AttentionLayer.  x_in: fp32 tokens of layer 0 (null for later layers: the input is then LN_ffn[layer-1](w.y)).
+template <typename T>
+int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv, const uint16_t* wp, const float* pp, int layer,
+                  const TfDims& d, const TfWs& w, hipStream_t s) {
+  const int M = d.B * d.T, D = d.D, dh = D / d.H;
+  const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
+  const float scale = 1.0f / sqrtf((float)dh);
+  auto W = [&](int slot) { return wp + vmc_tfam_pack_offset(slot, layer, D, d.ff, d.L, d.C); };
+  auto P = [&](int slot, int l) { return pp + vmc_tfam_pack_offset(slot, l, D, d.ff, d.L, d.C); };
+  int rc;
+  const float* resid;
+  {  // 1: qkv
+    TfArgs a = {};
+    a.M = M; a.N = 3 * D; a.K = D; a.rpb = rpb;
+    a.W = W(VMC_TFAM_W_SELF_IN); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_IN_B, layer);
+    a.out = w.qkv; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
+    if (x_in != nullptr) {
+      a.A = x_in; a.lda = D;
+      rc = tf_gemm_kd<T, PRO_F32, EPI_ACT16>(a, 16, D, s);
+      resid = x_in;
+    } else {
+      a.A = w.y; a.lda = D; a.eps = 1e-5f;
+      a.ln_g = P(VMC_TFAM_P_NORM_FFN, layer - 1); a.ln_b = a.ln_g + D; a.xout = w.xa;
+      rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s);
+      resid = w.xa;
+    }
+    if (rc) return rc;
+  }
+  const int bn_attn = 16;
+  {  // 2: y = resid + selfattn(qkv) Wo^T + b
+    TfArgs a = {};
+    a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
+    a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D;
+    a.kmask = mask; a.T = d.T; a.Tk = d.T; a.H = d.H; a.B = d.B; a.scale = scale;
+    a.W = W(VMC_TFAM_W_SELF_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_OUT_B, layer);
+    a.resid = resid; a.ldres = D; a.out = w.y; a.ldo = D;
+    if ((rc = tf_dispatch_attn<T>(a, bn_attn, dh, s))) return rc;
+  }
+  const float* ln_g = P(VMC_TFAM_P_NORM_SELF, layer);
+  const float* x2 = nullptr;
+  if (d.has_cross) {
+    {  // 3: q = LN_self(y) Wq^T + b ; xb = LN_self(y)
+      TfArgs a = {};
+      a.M = M; a.N = D; a.K = D; a.rpb = rpb;
+      a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xb;
+      a.W = W(VMC_TFAM_W_CROSS_Q); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_Q_B, layer);
+      a.out = w.q; a.ldo = D; a.act = VMC_ACT_NONE;
+      if ((rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s))) return rc;
+    }
+    {  // 4: y = xb + crossattn(q, K_l, V_l) Wo^T + b
+      TfArgs a = {};
+      a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
+      a.q = w.q; a.ldq = D;
+      a.k = w.kv + (size_t)layer * 2 * D; a.v = a.k + D; a.ldk = a.ldv = d.L * 2 * D;
+      a.kmask = mask_kv; a.T = d.T; a.Tk = d.Tk; a.H = d.H; a.B = d.B; a.scale = scale;
+      a.W = W(VMC_TFAM_W_CROSS_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_OUT_B, layer);
+      a.resid = w.xb; a.ldres = D; a.out = w.y; a.ldo = D;
+      if ((rc = tf_dispatch_attn<T>(a, bn_attn, dh, s))) return rc;
+    }
+    ln_g = P(VMC_TFAM_P_NORM_CROSS, layer);
+  }
+  {  // 5: h = relu(LN(y) W1^T + b) ; xa = LN(y)
+    TfArgs a = {};
+    a.M = M; a.N = d.ff; a.K = D; a.rpb = rpb;
+    a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xa;
+    a.W = W(VMC_TFAM_W_FFN0); a.ldw = D; a.bias = P(VMC_TFAM_P_FFN0_B, layer);
+    a.out = w.h; a.ldo = d.ff; a.act = VMC_ACT_RELU;
+    if ((rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s))) return rc;
+    x2 = w.xa;
+  }
+  {  // 6: y = xa + h W2^T + b
+    TfArgs a = {};
+    a.M = M; a.N = D; a.K = d.ff; a.rpb = rpb;
+    a.A = w.h; a.lda = d.ff;
+    a.W = W(VMC_TFAM_W_FFN3); a.ldw = d.ff; a.bias = P(VMC_TFAM_P_FFN3_B, layer);
+    a.resid = x2; a.ldres = D; a.out = w.y; a.ldo = D;
+    if ((rc = tf_launch_ring<T, 16, 512, 3>(a, s))) return rc;
+  }
+  return 0;
+}
+
+template <typename T>
+int tf_head_impl(const uint16_t* wp, const float* pp, float* logits, const TfDims& d, const TfWs& w, hipStream_t s) {
+  const int D = d.D;
+  const float* lnf = pp + vmc_tfam_pack_offset(VMC_TFAM_P_NORM_FFN, d.L - 1, D, d.ff, d.L, d.C);
+  const float* lnc = pp + vmc_tfam_pack_offset(VMC_TFAM_P_CLS_LN, 0, D, d.ff, d.L, d.C);
+  if (D == 768) hipLaunchKernelGGL((tf_pool_kernel<T, 768>), dim3(d.B), dim3(256), 0, s, w.y, lnf, lnf + D, lnc, lnc + D, w.pool, d.T, 1e-5f);
+  else hipLaunchKernelGGL((tf_pool_kernel<T, 512>), dim3(d.B), dim3(256), 0, s, w.y, lnf, lnf + D, lnc, lnc + D, w.pool, d.T, 1e-5f);
+  VMC_CHECK_LAUNCH();
+  int rc;
+  {
+    TfArgs a = {};
+    a.M = d.B; a.N = D / 2; a.K = D; a.rpb = 32;
+    a.A = w.pool; a.lda = D;
+    a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_CLS1, 0, D, d.ff, d.L, d.C); a.ldw = D;
+    a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_CLS1_B, 0, D, d.ff, d.L, d.C);
+    a.out = w.g; a.ldo = D / 2; a.act = VMC_ACT_GELU_ERF;
+    if ((rc = tf_gemm_kd<T, PRO_16, EPI_ACT16>(a, 16, D, s))) return rc;
+  }
+  {
+    TfArgs a = {};
+    a.M = d.B; a.N = d.C; a.K = D / 2; a.rpb = 32;
+    a.A = w.g; a.lda = D / 2;
+    a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_CLS4, 0, D, d.ff, d.L, d.C); a.ldw = D / 2;
+    a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_CLS4_B, 0, D, d.ff, d.L, d.C);
+    a.out = logits; a.ldo = d.C;
+    if ((rc = tf_gemm_kd<T, PRO_16, EPI_BIAS32>(a, 16, D, s))) return rc;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t vmc_tfam_workspace_bytes(int B, int T, int Tk, int D, int ff, int L, int C, int has_cross) {
+  TfDims d = {B, T, Tk, D, 8, ff, L, C, has_cross};
+  return tf_ws(nullptr, d).bytes;
+}
+
+#define TF_DT(call)                                   \
+  if (dtype16 == VMC_BF16) return call<BF16>;         \
+  if (dtype16 == VMC_F16) return call<F16>;           \
+  return VMC_E_DTYPE
+
+extern "C" int vmc_tfam_kv_fwd(const float* motion, const void* wpack, const float* ppack, void* ws, size_t ws_bytes, int B, int T, int Tk,
+                               int D, int H, int ff, int L, int C, int dtype16, void* stream) {
+  TfDims d = {B, T, Tk, D, H, ff, L, C, 1};
+  if (int rc = tf_check(d)) return rc;
+  const TfWs w = tf_ws(ws, d);
+  if (ws == nullptr || ws_bytes < w.bytes) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16) return tf_kv_impl<BF16>(motion, (const uint16_t*)wpack, ppack, d, w, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return tf_kv_impl<F16>(motion, (const uint16_t*)wpack, ppack, d, w, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_tfam_layer_fwd(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv, const void* wpack, const float* ppack,
+                                  int layer, void* ws, size_t ws_bytes, int B, int T, int Tk, int D, int H, int ff, int L, int C,
+                                  int has_cross, int dtype16, void* stream) {
+  TfDims d = {B, T, Tk, D, H, ff, L, C, has_cross};
+  if (int rc = tf_check(d)) return rc;
+  if (layer < 0 || layer >= L || (layer == 0) != (x_in != nullptr)) return VMC_E_ARG;
+  const TfWs w = tf_ws(ws, d);
+  if (ws == nullptr || ws_bytes < w.bytes) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16)
+    return tf_layer_impl<BF16>(x_in, mask, mask_kv, (const uint16_t*)wpack, ppack, layer, d, w, (hipStream_t)stream);
+  if (dtype16 == VMC_F16)
+    return tf_layer_impl<F16>(x_in, mask, mask_kv, (const uint16_t*)wpack, ppack, layer, d, w, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_tfam_head_fwd(const void* wpack, const float* ppack, float* logits, void* ws, size_t ws_bytes, int B, int T, int Tk, int D,
+                                 int H, int ff, int L, int C, int has_cross, int dtype16, void* stream) {
+  TfDims d = {B, T, Tk, D, H, ff, L, C, has_cross};
+  if (int rc = tf_check(d)) return rc;
+  const TfWs w = tf_ws(ws, d);
+  if (ws == nullptr || ws_bytes < w.bytes) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16) return tf_head_impl<BF16>((const uint16_t*)wpack, ppack, logits, d, w, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return tf_head_impl<F16>((const uint16_t*)wpack, ppack, logits, d, w, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_tfam_forward(const float* x, const float* motion, const uint8_t* mask, const uint8_t* mask_kv, const void* wpack,
+                                const float* ppack, float* logits, void* ws, size_t ws_bytes, int B, int T, int Tk, int D, int H, int ff,
+                                int L, int C, int has_cross, int dtype16, void* stream) {
+  int rc;
+  if (has_cross && (rc = vmc_tfam_kv_fwd(motion, wpack, ppack, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, dtype16, stream))) return rc;
+  for (int l = 0; l < L; ++l)
+    if ((rc = vmc_tfam_layer_fwd(l == 0 ? x : nullptr, mask, mask_kv, wpack, ppack, l, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, has_cross,
+                                 dtype16, stream)))
+      return rc;
+  return vmc_tfam_head_fwd(wpack, ppack, logits, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, has_cross, dtype16, stream);
+}

@@ -75,7 +75,9 @@ class FusedAdam:
     def step(self, grad_scale: float = 1.0, max_grad_norm=None):
         a = self.arena
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
-            total = float(a.grad_norm().item())
+            # the norm torch.nn.utils.clip_grad_norm_ sees is that of the AVERAGED gradient: the arena holds the SUM over
+            # ranks until grad_scale (1/world) is applied inside the Adam kernel
+            total = float(a.grad_norm().item()) * abs(grad_scale)
             grad_scale = grad_scale * min(1.0, max_grad_norm / (total + 1e-6))
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
