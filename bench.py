@@ -49,6 +49,77 @@ def _time_cuda(fn, iters, warmup=3):
     return (time.perf_counter() - t0) / iters
 
 
+def tfam_hbm_bytes(B, T=16, Tk=16, D=768, ff=2048, L=4, C=140, e_w=2):
+    """BYTES_fwd(B) = P_used*e_w + B*(T_r+T_f)*D*e_a + B*(T_r+T_f) + B*C*4 (cross mode: every parameter but
+    the unused projection_layer; fp32 tokens in, u8 masks in, fp32 logits out)."""
+    p_layer = 2 * (3 * D * D + 3 * D) + 2 * (D * D + D) + (ff * D + ff) + (D * ff + D) + 6 * D
+    p_used = L * p_layer + 2 * D + (D // 2) * D + D // 2 + C * (D // 2) + C
+    return p_used * e_w + B * (T + Tk) * D * 4 + B * (T + Tk) + B * C * 4, p_used
+
+
+def tfam_forward_block(dev, rank, cdt, batches=(8, 16, 64), iters=200):
+    """TFAM eval forward at the reference's small batches (BASELINE.json configs[3]; north_star: 'TFAM fusion step on 16x768
+    tokens at >= 70 % HBM roofline'): the fused launch chain (vmc_tfam_forward) captured in ONE hipGraph, timed with HIP
+    events on the replay stream, (a) back to back = weights MALL-resident (63.7 MB < 256 MiB Infinity Cache) and (b) with
+    512 MiB streamed through another buffer between replays = weights evicted to HBM (SURVEY.md 8d protocol).  Below B ~ 20
+    the bound is HBM (weight stream); above it the MFMA fraction is the one to read."""
+    from vimo_clip_amd import synth
+    from vimo_clip_amd.graphs import GraphedCallable
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+
+    m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0,
+                 device=dev, compute_dtype=cdt).to(dev).eval()
+    m.load_state_dict(synth.tfam_state_dict(768, 8, 4, 2048, 140, 4), strict=True)
+    evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    flops_clip = 1.0136e9
+    out = {}
+    for B in batches:
+        rgb = synth.normal(10 + rank, f"rgb{B}", (B, 16, 768)).to(dev)
+        mot = synth.normal(10 + rank, f"mot{B}", (B, 16, 768)).to(dev)
+        mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
+
+        def fwd(r, f, a, b):
+            with torch.no_grad():
+                return m(r, f, mask_rgb=a, mask_flow=b)
+        row = {}
+        for label, fused in (("fused_chain", True), ("per_op", False)):
+            m.fused_inference = fused
+            g = GraphedCallable(fwd, rgb, mot, mk, mk)
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t_res = e0.elapsed_time(e1) * 1e-3 / iters
+            ts = []
+            for _ in range(max(10, iters // 10)):
+                evict.add_(1)                                  # 512 MiB read + 512 MiB written: the weights leave L2 and MALL
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                g.replay()
+                e.record()
+                ts.append((s, e))
+            torch.cuda.synchronize()
+            cold = sorted(s.elapsed_time(e) * 1e-3 for s, e in ts)
+            t_cold = cold[len(cold) // 2]
+            nbytes, _ = tfam_hbm_bytes(B)
+            row[label] = {"us_mall_resident": round(t_res * 1e6, 2), "us_evicted": round(t_cold * 1e6, 2),
+                          "clips_per_s_mall_resident": round(B / t_res, 1), "clips_per_s_evicted": round(B / t_cold, 1),
+                          "hbm_frac_mall_resident": round(nbytes / t_res / 8e12, 4), "hbm_frac_evicted": round(nbytes / t_cold / 8e12, 4),
+                          "mfma_frac": round(B / t_res * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+            del g
+        m.fused_inference = True
+        row["bytes_fwd"] = tfam_hbm_bytes(B)[0]
+        out[f"B{B}"] = row
+    return {"bound": "hbm (B <~ 20) / mfma", "peak": 8000.0, "unit": "GB/s", "launches_per_forward": 1 + 6 * 4 + 3,
+            "note": "one hipGraph replay per forward, HIP events on the replay stream; evicted = 512 MiB streamed between replays",
+            **out}
+
+
 def tfam_extras(dev, rank, world, cdt):
     """TFAM (BASELINE.json configs[3]): d_model 768, 8 heads, 4 layers, ff 2048, 16x768 RGB + motion tokens,
     cross-attention.  Forward clips/s at small and large batch; full train step (fwd + bwd + gradient all-reduce
@@ -141,6 +212,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the TFAM measurements")
     ap.add_argument("--no-fuse-add-ln", action="store_true", help="A/B: residual add in the GEMM epilogue + plain LayerNorm")
+    ap.add_argument("--only", default="", choices=["", "tfam"], help="builder shortcut: run one secondary leg alone and print it")
     ap.add_argument("--chunk", type=int, default=0, help="frames per encoder pass inside a step (0 = all frames of the step at once)")
     args = ap.parse_args()
 
@@ -166,6 +238,9 @@ def main():
     from vimo_clip_amd.clip_vit import VisionTransformer
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if args.only == "tfam":
+        print(json.dumps(tfam_forward_block(dev, rank, cdt)), flush=True)
+        return
     model = VisionTransformer.from_name(args.model, compute_dtype=cdt).to(dev).eval()
     sd = synth.vit_state_dict(args.model, seed=2)
     model.load_state_dict(sd, strict=True)

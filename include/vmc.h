@@ -301,12 +301,19 @@ enum {
   VMC_TFAM_P_CLS_LN, VMC_TFAM_P_CLS1_B, VMC_TFAM_P_CLS4_B, VMC_TFAM_P_END
 };
 long long vmc_tfam_pack_offset(int slot, int layer, int D, int ff, int L, int C);
+/* Pack-time helper for the three linears that consume a LayerNorm output (self_attn.in_proj of layers >= 1 <- norm_ffn of the
+ * previous layer; cross_attn q rows <- norm_self; ffn.0 <- norm_cross, or norm_self when has_cross = 0): the chain feeds them
+ * the STANDARDISED rows z = (y - mean) * rstd and expects the affine part folded in,
+ *   w16_out[r, k] = W[r, k] * gamma[k],   bias_out[r] = bias[r] + sum_k W[r, k] * beta[k]
+ * (LN(y) W^T + b = z (W . gamma)^T + (b + W beta)).  W fp32 [rows, cols] contiguous; every other slot is a plain cast / copy. */
+int vmc_tfam_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, void* w16_out,
+                            float* bias_out, int rows, int cols, int dtype16, void* stream);
 /* Scratch for one forward of B clips (activations of one layer at a time + the hoisted K|V); caller-owned. */
 size_t vmc_tfam_workspace_bytes(int B, int T, int Tk, int D, int ff, int L, int C, int has_cross);
 /* Hoisted cross-attention K|V: ws.kv[B*Tk, L*2D] = motion[B*Tk, D] (fp32) x kv_all^T + bias  (AMO_CLIP.py:43-45, all layers). */
 int vmc_tfam_kv_fwd(const float* motion, const void* wpack, const float* ppack, void* workspace, size_t workspace_bytes,
                     int B, int T, int Tk, int D, int H, int ff, int L, int C, int dtype16, void* stream);
-/* One AttentionLayer (AMO_CLIP.py:37-51).  Layer 0 reads the fp32 tokens x_in [B*T, D]; later layers (x_in = NULL)
+/* One AttentionLayer (AMO_CLIP.py:37-51); wpack / ppack as described above, with the LayerNorm-consuming slots folded.  Layer 0 reads the fp32 tokens x_in [B*T, D]; later layers (x_in = NULL)
  * continue from the pre-LayerNorm sum the previous layer left in the workspace.  mask [B,T] / mask_kv [B,Tk]: 1 = real
  * token (the reference's mask_rgb / mask_flow before inversion, :125-126), NULL = all real.  has_cross = 0: self
  * attention + FFN only (rgb-only / flow-only / concatenated-token modes, :136-147,:159-167). */

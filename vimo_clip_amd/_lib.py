@@ -66,6 +66,7 @@ SIGNATURES = {
     "vmc_bce_loss": (I, [P, P, P, P, I, F, P, Z, P]),
     "vmc_cross_entropy_loss": (I, [P, P, P, P, P, I, I, P, Z, P]),
     "vmc_tfam_pack_offset": (ctypes.c_longlong, [I, I, I, I, I, I]),
+    "vmc_tfam_fold_layernorm": (I, [P, P, P, P, P, P, I, I, I, P]),
     "vmc_tfam_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
     "vmc_tfam_kv_fwd": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, I, I, P]),
     "vmc_tfam_layer_fwd": (I, [P, P, P, P, P, I, P, Z, I, I, I, I, I, I, I, I, I, I, P]),

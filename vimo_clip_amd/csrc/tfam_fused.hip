@@ -97,6 +97,9 @@ __device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0,
 
 // ---- A operand producers --------------------------------------------------------------------------------------------
 // thread t: row t>>3, 8 threads per row, float4 at columns 4*(t8 + 8 i).
+// The GEMM consumes z = (y - mean) * rstd: gamma is folded into the packed weight columns and beta W^T into the packed bias
+// (LN(y) W^T + b = z (W . gamma)^T + (b + W beta)), so the 32 row groups do not each re-read gamma and beta.  The fp32 side
+// output x = z * gamma + beta (the residual operand of a later launch) needs them only for this block's BN columns.
 template <typename T, int KD, int BN>
 __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, int nt, int tid) {
   constexpr int NI = KD / 32;
@@ -124,13 +127,14 @@ __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, 
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int c4 = t8 + 8 * i;
-    const float4 g = *(const float4*)(a.ln_g + 4 * c4), b = *(const float4*)(a.ln_b + 4 * c4);
-    float4 y;
-    y.x = x[i].x * rstd * g.x + b.x; y.y = x[i].y * rstd * g.y + b.y;
-    y.z = x[i].z * rstd * g.z + b.z; y.w = x[i].w * rstd * g.w + b.w;
-    if (emit && (4 * c4) / BN == nt) *(float4*)(xo + 4 * c4) = y;  // this block's BN columns of the fp32 side output
+    float4 z;
+    z.x = x[i].x * rstd; z.y = x[i].y * rstd; z.z = x[i].z * rstd; z.w = x[i].w * rstd;
+    if (emit && (4 * c4) / BN == nt) {            // this block's BN columns of the fp32 side output
+      const float4 g = *(const float4*)(a.ln_g + 4 * c4), b = *(const float4*)(a.ln_b + 4 * c4);
+      *(float4*)(xo + 4 * c4) = make_float4(z.x * g.x + b.x, z.y * g.y + b.y, z.z * g.z + b.z, z.w * g.w + b.w);
+    }
     *(uint2*)(a_img + row * (KD * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
-        make_uint2(pack2<T>(y.x, y.y), pack2<T>(y.z, y.w));
+        make_uint2(pack2<T>(z.x, z.y), pack2<T>(z.z, z.w));
   }
 }
 
@@ -168,11 +172,11 @@ __device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, 
   }
 }
 
-// V rows of the block's clips -> LDS image [(cpb-1)*Tk + 32 rows][D] by LDS-DMA (rows past the data repeat the last key:
-// finite values under a zero probability).
-__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int wave, int lane) {
+// V rows of the block's clips -> LDS image [vrows][D] by LDS-DMA: vrows = (cpb-1)*Tk + 16*NKT, NKT = key tiles (Tk <= 16: keys
+// 16..31 of the 32-key P V step are fed as zeros, no LDS rows); rows past the data repeat the last key (finite values under
+// a zero probability).
+__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int vrows, int wave, int lane) {
   const int cpr = a.K >> 3;
-  const int vrows = (a.cpb - 1) * a.Tk + 32;
   const int total = (vrows * cpr + 63) >> 6;
   const int c0 = rb * a.cpb;
   for (int ii = wave; ii < total; ii += 4) {
@@ -190,68 +194,99 @@ __device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb,
 // K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
 // of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
 // operand of the out_proj GEMM.
-template <typename T, int DH, int QT>
-__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, char* a_img, const char* v_img, int rb, int wave, int lane) {
+template <int DH, int QT, int NKT>
+struct TfAttnFrags {
+  static constexpr int KK = DH / 32, PB = 4 / QT;
+  uint4 kf[PB][NKT][KK], qf[PB][QT][KK];
+  uint32_t livebits[2];
+};
+
+// K / Q fragments of this wave's first PB (clip, head) pairs + the liveness of this lane's keys: plain global loads, issued
+// together with the LDS-DMA of the V and W images so that one round trip covers all of them.
+template <int DH, int QT, int NKT>
+__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT>& f, int rb, int p0, int lane) {
+  constexpr int KK = DH / 32, PB = 4 / QT;
+  const int r = lane & 15, q = lane >> 4;
+  const int c0 = rb * a.cpb, npairs = a.cpb * a.H;
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int p = min(p0 + i, npairs - 1);
+    const int ci = p / a.H, h = p - ci * a.H;
+    const int clip = min(c0 + ci, a.B - 1);
+#pragma unroll
+    for (int nt = 0; nt < NKT; ++nt) {
+      const uint16_t* kr = a.k + ((size_t)clip * a.Tk + min(16 * nt + r, a.Tk - 1)) * a.ldk + h * DH + 8 * q;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(kr + 32 * kk);
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const uint16_t* qr = a.q + ((size_t)clip * a.T + min(16 * qt + r, a.T - 1)) * a.ldq + h * DH + 8 * q;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(qr + 32 * kk);
+    }
+  }
+}
+
+__device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebits)[2], int rb, int lane) {
+  const int q = lane >> 4, c0 = rb * a.cpb;
+  livebits[0] = livebits[1] = 0u;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int clip = min(c0 + min(ci, a.cpb - 1), a.B - 1);
+    uint32_t lo = 0x01010101u, hi = 0x01010101u;                  // mask bytes of keys 4q..4q+3 and 16+4q..
+    if (a.kmask != nullptr) {
+      const uint8_t* mk = a.kmask + (size_t)clip * a.Tk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 4 * q + j, k1 = 16 + 4 * q + j;
+        const uint32_t m0 = mk[min(k0, a.Tk - 1)], m1 = mk[min(k1, a.Tk - 1)];
+        lo = (lo & ~(0xFFu << (8 * j))) | ((m0 ? 1u : 0u) << (8 * j));
+        hi = (hi & ~(0xFFu << (8 * j))) | ((m1 ? 1u : 0u) << (8 * j));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (4 * q + j < a.Tk && ((lo >> (8 * j)) & 1u)) livebits[ci] |= 1u << j;
+      if (16 + 4 * q + j < a.Tk && ((hi >> (8 * j)) & 1u)) livebits[ci] |= 1u << (4 + j);
+    }
+  }
+}
+
+// Masked attention of the block's (clip, head) pairs; one wave per pair, PB pairs in flight per wave.  S^T = K Q^T with the
+// K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
+// of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
+// operand of the out_proj GEMM.
+template <typename T, int DH, int QT, int NKT>
+__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT>& f, char* a_img, const char* v_img, int rb, int wave,
+                                            int lane) {
   constexpr int KK = DH / 32, DT = DH / 16, PB = 4 / QT;
   const int r = lane & 15, q = lane >> 4;
-  const int c0 = rb * a.cpb;
   const int npairs = a.cpb * a.H;
   const int rowb = a.K * 2;
   const float c2 = a.scale * 1.4426950408889634f;
   const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
-  // key liveness of this lane's keys (16 nt + 4 q + j) per clip of the block
-  uint32_t livebits[2] = {0u, 0u};
-#pragma unroll
-  for (int ci = 0; ci < 2; ++ci) {
-    const int clip = min(c0 + min(ci, a.cpb - 1), a.B - 1);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = 16 * nt + 4 * q + j;
-        bool live = key < a.Tk;
-        if (live && a.kmask != nullptr) live = a.kmask[(size_t)clip * a.Tk + key] != 0;
-        livebits[ci] |= (live ? 1u : 0u) << (4 * nt + j);
-      }
-  }
   for (int p0 = wave * PB; p0 < npairs; p0 += 4 * PB) {
-    uint4 kf[PB][2][KK], qf[PB][QT][KK];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int p = min(p0 + i, npairs - 1);
-      const int ci = p / a.H, h = p - ci * a.H;
-      const int clip = min(c0 + ci, a.B - 1);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const uint16_t* kr = a.k + ((size_t)clip * a.Tk + min(16 * nt + r, a.Tk - 1)) * a.ldk + h * DH + 8 * q;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[i][nt][kk] = *(const uint4*)(kr + 32 * kk);
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        const uint16_t* qr = a.q + ((size_t)clip * a.T + min(16 * qt + r, a.T - 1)) * a.ldq + h * DH + 8 * q;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) qf[i][qt][kk] = *(const uint4*)(qr + 32 * kk);
-      }
-    }
+    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       if (p0 + i >= npairs) break;                 // wave-uniform
       const int p = p0 + i;
       const int ci = p / a.H, h = p - ci * a.H;
-      const uint32_t lb = ci ? livebits[1] : livebits[0];
+      const uint32_t lb = ci ? f.livebits[1] : f.livebits[0];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         f32x4 s[2];
+        s[1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // NKT == 1: keys 16..31 do not exist
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NKT; ++nt) {
           s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kk = 0; kk < KK; ++kk) s[nt] = T::mfma16(kf[i][nt][kk], qf[i][qt][kk], s[nt]);
+          for (int kk = 0; kk < KK; ++kk) s[nt] = T::mfma16(f.kf[i][nt][kk], f.qf[i][qt][kk], s[nt]);
         }
         float m = -INFINITY;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (!((lb >> (4 * nt + j)) & 1u)) s[nt][j] = -INFINITY;
@@ -263,8 +298,11 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, char* a_img, const 
         uint4 pf;
         pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][1], c2, -mc)));
         pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][3], c2, -mc)));
-        pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][1], c2, -mc)));
-        pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][3], c2, -mc)));
+        pf.z = pf.w = 0u;
+        if constexpr (NKT == 2) {
+          pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][1], c2, -mc)));
+          pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][3], c2, -mc)));
+        }
         f32x4 osum = T::mfma16(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f});
         f32x4 o[DT];
         // transposed 4-key x 16-column blocks: this lane supplies key row 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
@@ -275,8 +313,9 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, char* a_img, const 
           const char* p0a = v_img + vrow0 * rowb + (swz16(col >> 3, vrow0) << 4) + (((col >> 2) & 1) << 3);
           const char* p1a = v_img + (vrow0 + 16) * rowb + (swz16(col >> 3, vrow0 + 16) << 4) + (((col >> 2) & 1) << 3);
           const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0a);
-          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a);
-          const uint2 x0 = __builtin_bit_cast(uint2, v0), x1 = __builtin_bit_cast(uint2, v1);
+          uint2 x1 = make_uint2(0u, 0u);
+          if constexpr (NKT == 2) x1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a));
+          const uint2 x0 = __builtin_bit_cast(uint2, v0);
           o[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pf, (f32x4){0.f, 0.f, 0.f, 0.f});
         }
         const float inv = 1.0f / osum[0];
@@ -329,50 +368,65 @@ __device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, 
 
 // ---- single-shot K kernel ----------------------------------------------------------------------------------------------
 // LDS: [A image 32 x K][W image BN x K][k-half exchange 2 x NTN x 1 KiB][V image (PRO_ATTN)]
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT>
-__global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
+// Every global access of the prologue (A rows / LayerNorm parameters / K, Q fragments / mask bytes / the LDS-DMA of the W
+// and V images) is issued before the first wait, so a workgroup pays ONE memory round trip before its MFMAs.
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT>
+__device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_smem) {
   constexpr int NTN = BN / 16;
+  constexpr int ROWB = KD * 2;
+  constexpr int KSTEPS = KD / 64;                // 32-wide k-steps per K half
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int nt, rb;
-  tf_block_map(blockIdx.x, a.n_tiles, a.n_rb, nt, rb);
-  const int rowb = a.K * 2;
+  tf_block_map(bid, a.n_tiles, a.n_rb, nt, rb);
   char* a_img = tf_smem;
-  char* w_img = a_img + TF_BM * rowb;
-  char* red = w_img + BN * rowb;
+  char* w_img = a_img + TF_BM * ROWB;
+  char* red = w_img + BN * ROWB;
   char* v_img = red + 2 * NTN * 1024;
   const int n0 = nt * BN;
 
-  tf_stage_w(a, w_img, n0, BN, wave, lane);
-  if constexpr (PRO == PRO_ATTN) tf_stage_v(a, v_img, rb, wave, lane);
-  if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane);
-  if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN>(a, a_img, rb, nt, tid);
-  if constexpr (PRO == PRO_F32) tf_pro_f32<T>(a, a_img, rb, tid);
   if constexpr (PRO == PRO_ATTN) {
+    TfAttnFrags<DH, QT, NKT> fr;
+    tf_attn_load<DH, QT, NKT>(a, fr, rb, wave * (4 / QT), lane);
+    tf_attn_live(a, fr.livebits, rb, lane);
+    tf_stage_v(a, v_img, rb, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane);
+    tf_stage_w(a, w_img, n0, BN, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                             // V (and W) images complete
-    tf_pro_attn<T, DH, QT>(a, a_img, v_img, rb, wave, lane);
+    tf_pro_attn<T, DH, QT, NKT>(a, fr, a_img, v_img, rb, wave, lane);
+  } else {
+    tf_stage_w(a, w_img, n0, BN, wave, lane);
+    if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane);
+    if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN>(a, a_img, rb, nt, tid);
+    if constexpr (PRO == PRO_F32) tf_pro_f32<T>(a, a_img, rb, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int r = lane & 15, q = lane >> 4;
   const int rt = wave & 1, ks = wave >> 1;
-  const int ksteps = a.K >> 6;                   // 32-wide k-steps per K half
   f32x4 acc[NTN];
 #pragma unroll
   for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int arow = 16 * rt + r;
-  const char* ap = a_img + arow * rowb;
-  for (int kk = 0; kk < ksteps; ++kk) {
-    const int chunk = (ks * ksteps + kk) * 4 + q;
-    const uint4 af = *(const uint4*)(ap + (swz16(chunk, arow) << 4));
+  const char* ap = a_img + arow * ROWB;
+  constexpr int KB = KSTEPS % 4 == 0 ? 4 : (KSTEPS % 3 == 0 ? 3 : (KSTEPS % 2 == 0 ? 2 : 1));   // k-steps whose reads are batched
 #pragma unroll
-    for (int n = 0; n < NTN; ++n) {
-      const int wrow = 16 * n + r;
-      const uint4 wf = *(const uint4*)(w_img + wrow * rowb + (swz16(chunk, wrow) << 4));
-      acc[n] = T::mfma16(wf, af, acc[n]);
+  for (int k0 = 0; k0 < KSTEPS; k0 += KB) {
+    uint4 af[KB], wf[KB][NTN];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int chunk = (ks * KSTEPS + k0 + kk) * 4 + q;
+      af[kk] = *(const uint4*)(ap + (swz16(chunk, arow) << 4));
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) {
+        const int wrow = 16 * n + r;
+        wf[kk][n] = *(const uint4*)(w_img + wrow * ROWB + (swz16(chunk, wrow) << 4));
+      }
     }
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+      for (int n = 0; n < NTN; ++n) acc[n] = T::mfma16(wf[kk][n], af[kk], acc[n]);
   }
   if (ks == 1) {
 #pragma unroll
@@ -389,6 +443,21 @@ __global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
       }
     }
   }
+}
+
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT>
+__global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
+  tf_gemm_body<T, BN, PRO, EPI, KD, DH, QT, NKT>(a, blockIdx.x, tf_smem);
+}
+
+// Two independent problems of the same kind in one launch (layer 0's qkv projection + the hoisted K|V projection of the
+// motion tokens: neither depends on the other, so the K|V GEMM costs no launch of its own).
+template <typename T, int BN, int PRO, int EPI, int KD>
+__global__ void __launch_bounds__(TF_NTH) tf_gemm_pair_kernel(const TfArgs a, const TfArgs b, int blocks_a) {
+  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
+  if ((int)blockIdx.x < blocks_a) tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1>(a, blockIdx.x, tf_smem);
+  else tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1>(b, blockIdx.x - blocks_a, tf_smem);
 }
 
 // ---- chunked-K kernel (FFN second linear): A 16-bit and W both by LDS-DMA through an NST-deep ring -----------------------
@@ -559,25 +628,69 @@ __global__ void __launch_bounds__(256) tf_pool_kernel(const float* __restrict__ 
   }
 }
 
+// ---- pack time: fold a LayerNorm's affine part into the linear that consumes it -------------------------------------------
+// w16[r, k] = W[r, k] * gamma[k] (16-bit), bias_out[r] = bias[r] + sum_k W[r, k] * beta[k] (fp32); one wave per row.
+template <typename T>
+__global__ void __launch_bounds__(256) tf_fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         uint16_t* __restrict__ w16, float* __restrict__ bias_out, int rows, int cols) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* wr = W + (size_t)row * cols;
+  float acc = 0.f;
+  for (int c = 4 * lane; c < cols; c += 256) {
+    const float4 w = *(const float4*)(wr + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    acc += (w.x * b.x + w.y * b.y) + (w.z * b.z + w.w * b.w);
+    *(uint2*)(w16 + (size_t)row * cols + c) = make_uint2(pack2<T>(w.x * g.x, w.y * g.y), pack2<T>(w.z * g.z, w.w * g.w));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) bias_out[row] = bias[row] + acc;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 constexpr size_t TF_LDS_MAX = 160 * 1024;
 
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT>
-int tf_launch(TfArgs& a, hipStream_t s) {
-  const size_t rowb = (size_t)a.K * 2;
-  size_t lds = TF_BM * rowb + BN * rowb + 2 * (BN / 16) * 1024;
-  if (PRO == PRO_ATTN) lds += (size_t)((a.cpb - 1) * a.Tk + 32) * rowb + 1024;   // + one LDS-DMA piece of slack
-  if (lds > TF_LDS_MAX) return VMC_E_SHAPE;
-  a.n_tiles = (a.N + BN - 1) / BN;
-  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
-  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT>;
-  static bool attr_done = false;                // per instantiation
-  if (!attr_done) {
+template <int BN, int PRO, int KD, int NKT>
+constexpr size_t tf_lds_bytes(int cpb, int Tk) {
+  return (size_t)(TF_BM + BN) * KD * 2 + 2 * (BN / 16) * 1024 +
+         (PRO == PRO_ATTN ? (size_t)((cpb - 1) * Tk + 16 * NKT) * KD * 2 + 1024 : 0);    // + one LDS-DMA piece of slack
+}
+
+template <typename K>
+int tf_set_lds(K kern, bool& done) {
+  if (!done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TF_LDS_MAX);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    done = true;
   }
+  return 0;
+}
+
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT = 1>
+int tf_launch(TfArgs& a, hipStream_t s) {
+  const size_t lds = tf_lds_bytes<BN, PRO, KD, NKT>(a.cpb, a.Tk);
+  if (lds > TF_LDS_MAX || a.K != KD) return VMC_E_SHAPE;
+  a.n_tiles = (a.N + BN - 1) / BN;
+  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
+  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT, NKT>;
+  static bool attr_done = false;                // per instantiation
+  if (int rc = tf_set_lds(kern, attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int BN, int PRO, int EPI, int KD>
+int tf_launch_pair(TfArgs& a, TfArgs& b, hipStream_t s) {
+  const size_t lds = tf_lds_bytes<BN, PRO, KD, 1>(1, 0);
+  if (lds > TF_LDS_MAX || a.K != KD || b.K != KD) return VMC_E_SHAPE;
+  a.n_tiles = (a.N + BN - 1) / BN; a.n_rb = (a.M + a.rpb - 1) / a.rpb;
+  b.n_tiles = (b.N + BN - 1) / BN; b.n_rb = (b.M + b.rpb - 1) / b.rpb;
+  auto kern = tf_gemm_pair_kernel<T, BN, PRO, EPI, KD>;
+  static bool attr_done = false;
+  if (int rc = tf_set_lds(kern, attr_done)) return rc;
+  const int na = a.n_tiles * a.n_rb;
+  hipLaunchKernelGGL(kern, dim3(na + b.n_tiles * b.n_rb), dim3(TF_NTH), lds, s, a, b, na);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -590,48 +703,60 @@ int tf_launch_ring(TfArgs& a, hipStream_t s) {
   a.n_rb = (a.M + a.rpb - 1) / a.rpb;
   auto kern = tf_gemm_ring_kernel<T, BN, KC, NST>;
   static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TF_LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
+  if (int rc = tf_set_lds(kern, attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
   VMC_CHECK_LAUNCH();
   return 0;
 }
 
-// output-column tile by row count: 16 columns while the launch is latency bound, wider tiles once the A rows re-read by
-// every column tile dominate the on-chip traffic
-inline int tf_pick_bn(int M, int N) {
-  if (N % 64 == 0 && M > 512) return 64;
-  if (N % 32 == 0 && M > 192) return 32;
-  return 16;
+// Output-column tile.  A workgroup's cost is one memory round trip plus (32 A rows + BN W rows) x K bytes at the ~70 GB/s one
+// CU pulls from L2, whatever BN is; what BN decides is how many workgroups there are.  Take the narrowest tile (most CUs
+// streaming W) whose grid still fits one resident round (2 workgroups per CU while the LDS footprint allows, else 1).
+inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn) {
+  const int n_rb = (M + rpb - 1) / rpb;
+  const int cands[4] = {16, 32, 48, 64};
+  int best = 16;
+  for (int i = 0; i < 4; ++i) {
+    const int bn = cands[i];
+    if (N % bn && !(N < bn)) continue;
+    if (attn && bn > 32) break;
+    const size_t lds = (size_t)(TF_BM + bn) * K * 2 + 2048 + (attn ? (size_t)48 * K * 2 : 0);
+    if (lds > TF_LDS_MAX) break;
+    best = bn;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    if ((long)((N + bn - 1) / bn) * n_rb <= 256L * per_cu) break;
+  }
+  return best;
 }
+
+#define TF_BN_SWITCH(bn, CALL)            \
+  switch (bn) {                           \
+    case 64: return CALL(64);             \
+    case 48: return CALL(48);             \
+    case 32: return CALL(32);             \
+    default: return CALL(16);             \
+  }
 
 template <typename T, int PRO, int EPI, int KD>
 int tf_dispatch_bn(TfArgs& a, int bn, hipStream_t s) {
-  if (bn == 64) return tf_launch<T, 64, PRO, EPI, KD, 64, 1>(a, s);
-  if (bn == 32) return tf_launch<T, 32, PRO, EPI, KD, 64, 1>(a, s);
-  return tf_launch<T, 16, PRO, EPI, KD, 64, 1>(a, s);
+#define TF_CALL(BNV) tf_launch<T, BNV, PRO, EPI, KD, 64, 1>(a, s)
+  TF_BN_SWITCH(bn, TF_CALL)
+#undef TF_CALL
 }
 
-template <typename T>
+template <typename T, int KD, int BN, int DH>
+int tf_dispatch_attn3(TfArgs& a, hipStream_t s) {
+  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 16 ? 2 : 1;
+  if (qt == 1 && nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 1>(a, s);
+  if (qt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 2>(a, s);
+  if (nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 2, 1>(a, s);
+  return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 2, 2>(a, s);
+}
+
+template <typename T, int KD>
 int tf_dispatch_attn(TfArgs& a, int bn, int dh, hipStream_t s) {
-  const int qt = a.T > 16 ? 2 : 1;
-#define TF_ATTN(BNV, DHV, QTV) return tf_launch<T, BNV, PRO_ATTN, EPI_RESID32, 0, DHV, QTV>(a, s)
-  if (bn == 32) {
-    if (dh == 64 && qt == 1) TF_ATTN(32, 64, 1);
-    if (dh == 64) TF_ATTN(32, 64, 2);
-    if (dh == 96 && qt == 1) TF_ATTN(32, 96, 1);
-    if (dh == 96) TF_ATTN(32, 96, 2);
-  } else {
-    if (dh == 64 && qt == 1) TF_ATTN(16, 64, 1);
-    if (dh == 64) TF_ATTN(16, 64, 2);
-    if (dh == 96 && qt == 1) TF_ATTN(16, 96, 1);
-    if (dh == 96) TF_ATTN(16, 96, 2);
-  }
-#undef TF_ATTN
-  return VMC_E_SHAPE;
+  if (bn == 32) return dh == 64 ? tf_dispatch_attn3<T, KD, 32, 64>(a, s) : tf_dispatch_attn3<T, KD, 32, 96>(a, s);
+  return dh == 64 ? tf_dispatch_attn3<T, KD, 16, 64>(a, s) : tf_dispatch_attn3<T, KD, 16, 96>(a, s);
 }
 
 struct TfDims {
@@ -721,30 +846,44 @@ inline TfWs tf_ws(void* base, const TfDims& d) {
 }
 
 template <typename T, int PRO, int EPI>
-int tf_gemm_kd(TfArgs& a, int bn, int D, hipStream_t s) {
-  if constexpr (PRO != PRO_LN) {
-    return tf_dispatch_bn<T, PRO, EPI, 0>(a, bn, s);
-  } else {
-    if (D == 768) return tf_dispatch_bn<T, PRO, EPI, 768>(a, bn, s);
-    return tf_dispatch_bn<T, PRO, EPI, 512>(a, bn, s);
+int tf_gemm_k(TfArgs& a, int bn, hipStream_t s) {
+  switch (a.K) {
+    case 768: return tf_dispatch_bn<T, PRO, EPI, 768>(a, bn, s);
+    case 512: return tf_dispatch_bn<T, PRO, EPI, 512>(a, bn, s);
+    case 384: if constexpr (PRO == PRO_16) return tf_dispatch_bn<T, PRO, EPI, 384>(a, bn, s); else return VMC_E_SHAPE;
+    case 256: if constexpr (PRO == PRO_16) return tf_dispatch_bn<T, PRO, EPI, 256>(a, bn, s); else return VMC_E_SHAPE;
+    default: return VMC_E_SHAPE;
   }
 }
 
-template <typename T>
-int tf_kv_impl(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w, hipStream_t s) {
+inline TfArgs tf_kv_args(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w) {
   TfArgs a = {};
   a.A = motion; a.lda = d.D;
   a.M = d.B * d.Tk; a.N = d.L * 2 * d.D; a.K = d.D; a.rpb = 32;
   a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_KV_ALL, 0, d.D, d.ff, d.L, d.C); a.ldw = d.D;
   a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, 0, d.D, d.ff, d.L, d.C);
   a.out = w.kv; a.ldo = a.N; a.act = VMC_ACT_NONE;
-  return tf_gemm_kd<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N), d.D, s);
+  return a;
+}
+
+template <typename T>
+int tf_kv_impl(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w, hipStream_t s) {
+  TfArgs a = tf_kv_args(motion, wp, pp, d, w);
+  return tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N, a.rpb, a.K, false), s);
+}
+
+// layer 0's qkv projection and the hoisted K|V projection in ONE launch (both read raw fp32 tokens, neither needs the other)
+template <typename T>
+int tf_qkv0_kv_pair(TfArgs& a, TfArgs& b, int bn, hipStream_t s) {
+#define TF_PAIR(BNV) (a.K == 768 ? tf_launch_pair<T, BNV, PRO_F32, EPI_ACT16, 768>(a, b, s) : tf_launch_pair<T, BNV, PRO_F32, EPI_ACT16, 512>(a, b, s))
+  TF_BN_SWITCH(bn, TF_PAIR)
+#undef TF_PAIR
 }
 
 // one AttentionLayer.  x_in: fp32 tokens of layer 0 (null for later layers: the input is then LN_ffn[layer-1](w.y)).
 template <typename T>
 int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv, const uint16_t* wp, const float* pp, int layer,
-                  const TfDims& d, const TfWs& w, hipStream_t s) {
+                  const TfDims& d, const TfWs& w, hipStream_t s, const float* merge_kv_motion = nullptr) {
   const int M = d.B * d.T, D = d.D, dh = D / d.H;
   const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
   const float scale = 1.0f / sqrtf((float)dh);
@@ -757,19 +896,25 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.M = M; a.N = 3 * D; a.K = D; a.rpb = rpb;
     a.W = W(VMC_TFAM_W_SELF_IN); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_IN_B, layer);
     a.out = w.qkv; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
+    const int bn = tf_pick_bn(M, a.N, rpb, D, false);
     if (x_in != nullptr) {
       a.A = x_in; a.lda = D;
-      rc = tf_gemm_kd<T, PRO_F32, EPI_ACT16>(a, 16, D, s);
+      if (merge_kv_motion != nullptr) {
+        TfArgs b = tf_kv_args(merge_kv_motion, wp, pp, d, w);
+        rc = tf_qkv0_kv_pair<T>(a, b, bn, s);
+      } else {
+        rc = tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, bn, s);
+      }
       resid = x_in;
     } else {
       a.A = w.y; a.lda = D; a.eps = 1e-5f;
       a.ln_g = P(VMC_TFAM_P_NORM_FFN, layer - 1); a.ln_b = a.ln_g + D; a.xout = w.xa;
-      rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s);
+      rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, bn, s);
       resid = w.xa;
     }
     if (rc) return rc;
   }
-  const int bn_attn = 16;
+  const int bn_attn = tf_pick_bn(M, D, rpb, D, true);
   {  // 2: y = resid + selfattn(qkv) Wo^T + b
     TfArgs a = {};
     a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
@@ -777,7 +922,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.kmask = mask; a.T = d.T; a.Tk = d.T; a.H = d.H; a.B = d.B; a.scale = scale;
     a.W = W(VMC_TFAM_W_SELF_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_OUT_B, layer);
     a.resid = resid; a.ldres = D; a.out = w.y; a.ldo = D;
-    if ((rc = tf_dispatch_attn<T>(a, bn_attn, dh, s))) return rc;
+    if ((rc = (D == 768 ? tf_dispatch_attn<T, 768>(a, bn_attn, dh, s) : tf_dispatch_attn<T, 512>(a, bn_attn, dh, s)))) return rc;
   }
   const float* ln_g = P(VMC_TFAM_P_NORM_SELF, layer);
   const float* x2 = nullptr;
@@ -788,7 +933,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
       a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xb;
       a.W = W(VMC_TFAM_W_CROSS_Q); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_Q_B, layer);
       a.out = w.q; a.ldo = D; a.act = VMC_ACT_NONE;
-      if ((rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s))) return rc;
+      if ((rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, tf_pick_bn(M, a.N, rpb, D, false), s))) return rc;
     }
     {  // 4: y = xb + crossattn(q, K_l, V_l) Wo^T + b
       TfArgs a = {};
@@ -798,7 +943,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
       a.kmask = mask_kv; a.T = d.T; a.Tk = d.Tk; a.H = d.H; a.B = d.B; a.scale = scale;
       a.W = W(VMC_TFAM_W_CROSS_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_OUT_B, layer);
       a.resid = w.xb; a.ldres = D; a.out = w.y; a.ldo = D;
-      if ((rc = tf_dispatch_attn<T>(a, bn_attn, dh, s))) return rc;
+      if ((rc = (D == 768 ? tf_dispatch_attn<T, 768>(a, bn_attn, dh, s) : tf_dispatch_attn<T, 512>(a, bn_attn, dh, s)))) return rc;
     }
     ln_g = P(VMC_TFAM_P_NORM_CROSS, layer);
   }
@@ -808,7 +953,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xa;
     a.W = W(VMC_TFAM_W_FFN0); a.ldw = D; a.bias = P(VMC_TFAM_P_FFN0_B, layer);
     a.out = w.h; a.ldo = d.ff; a.act = VMC_ACT_RELU;
-    if ((rc = tf_gemm_kd<T, PRO_LN, EPI_ACT16>(a, 16, D, s))) return rc;
+    if ((rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, tf_pick_bn(M, a.N, rpb, D, false), s))) return rc;
     x2 = w.xa;
   }
   {  // 6: y = xa + h W2^T + b
@@ -838,7 +983,7 @@ int tf_head_impl(const uint16_t* wp, const float* pp, float* logits, const TfDim
     a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_CLS1, 0, D, d.ff, d.L, d.C); a.ldw = D;
     a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_CLS1_B, 0, D, d.ff, d.L, d.C);
     a.out = w.g; a.ldo = D / 2; a.act = VMC_ACT_GELU_ERF;
-    if ((rc = tf_gemm_kd<T, PRO_16, EPI_ACT16>(a, 16, D, s))) return rc;
+    if ((rc = tf_gemm_k<T, PRO_16, EPI_ACT16>(a, 16, s))) return rc;
   }
   {
     TfArgs a = {};
@@ -847,11 +992,26 @@ int tf_head_impl(const uint16_t* wp, const float* pp, float* logits, const TfDim
     a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_CLS4, 0, D, d.ff, d.L, d.C); a.ldw = D / 2;
     a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_CLS4_B, 0, D, d.ff, d.L, d.C);
     a.out = logits; a.ldo = d.C;
-    if ((rc = tf_gemm_kd<T, PRO_16, EPI_BIAS32>(a, 16, D, s))) return rc;
+    if ((rc = tf_gemm_k<T, PRO_16, EPI_BIAS32>(a, 16, s))) return rc;
   }
   return 0;
 }
 }  // namespace
+
+extern "C" int vmc_tfam_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, void* w16_out,
+                                       float* bias_out, int rows, int cols, int dtype16, void* stream) {
+  if (!W || !bias || !gamma || !beta || !w16_out || !bias_out || rows <= 0 || cols <= 0) return VMC_E_ARG;
+  if (cols % 4) return VMC_E_SHAPE;
+  if (((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w16_out) & 7) return VMC_E_ALIGN;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL((tf_fold_ln_kernel<BF16>), grid, block, 0, (hipStream_t)stream, W, bias, gamma, beta, (uint16_t*)w16_out, bias_out, rows, cols);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL((tf_fold_ln_kernel<F16>), grid, block, 0, (hipStream_t)stream, W, bias, gamma, beta, (uint16_t*)w16_out, bias_out, rows, cols);
+  else return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" size_t vmc_tfam_workspace_bytes(int B, int T, int Tk, int D, int ff, int L, int C, int has_cross) {
   TfDims d = {B, T, Tk, D, 8, ff, L, C, has_cross};
@@ -903,11 +1063,19 @@ extern "C" int vmc_tfam_head_fwd(const void* wpack, const float* ppack, float* l
 extern "C" int vmc_tfam_forward(const float* x, const float* motion, const uint8_t* mask, const uint8_t* mask_kv, const void* wpack,
                                 const float* ppack, float* logits, void* ws, size_t ws_bytes, int B, int T, int Tk, int D, int H, int ff,
                                 int L, int C, int has_cross, int dtype16, void* stream) {
-  int rc;
-  if (has_cross && (rc = vmc_tfam_kv_fwd(motion, wpack, ppack, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, dtype16, stream))) return rc;
-  for (int l = 0; l < L; ++l)
-    if ((rc = vmc_tfam_layer_fwd(l == 0 ? x : nullptr, mask, mask_kv, wpack, ppack, l, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, has_cross,
-                                 dtype16, stream)))
-      return rc;
+  TfDims d = {B, T, Tk, D, H, ff, L, C, has_cross};
+  if (int rc = tf_check(d)) return rc;
+  if (!x || !wpack || !ppack || !logits || (has_cross && !motion)) return VMC_E_ARG;
+  const TfWs w = tf_ws(ws, d);
+  if (ws == nullptr || ws_bytes < w.bytes) return VMC_E_ARG;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  for (int l = 0; l < L; ++l) {
+    const float* xin = l == 0 ? x : nullptr;
+    const float* mkv = (l == 0 && has_cross) ? motion : nullptr;     // the hoisted K|V GEMM rides layer 0's first launch
+    const int rc = dtype16 == VMC_BF16 ? tf_layer_impl<BF16>(xin, mask, mask_kv, (const uint16_t*)wpack, ppack, l, d, w, s, mkv)
+                                       : tf_layer_impl<F16>(xin, mask, mask_kv, (const uint16_t*)wpack, ppack, l, d, w, s, mkv);
+    if (rc) return rc;
+  }
   return vmc_tfam_head_fwd(wpack, ppack, logits, ws, ws_bytes, B, T, Tk, D, H, ff, L, C, has_cross, dtype16, stream);
 }

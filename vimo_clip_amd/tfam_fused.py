@@ -74,6 +74,18 @@ class TfamPack:
         dst = self.wpack[off:off + rows * cols]
         check(lib.vmc_cast_weight(ptr(w), ptr(dst), None, rows, cols, cols, 0, dt(self.dtype16), stream()), "cast_weight")
 
+    def _put_folded(self, wslot, bslot, layer, w, b, norm):
+        """Linear fed by LayerNorm `norm`: weight columns scaled by gamma, bias += W beta (vmc_tfam_fold_layernorm)."""
+        w, b = w.detach(), b.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        b = b.float().contiguous()
+        rows, cols = w.shape
+        woff, boff = self._off(wslot, layer), self._off(bslot, layer)
+        check(lib.vmc_tfam_fold_layernorm(ptr(w), ptr(b), ptr(norm.weight.detach()), ptr(norm.bias.detach()),
+                                          ptr(self.wpack[woff:woff + rows * cols]), ptr(self.ppack[boff:boff + rows]), rows, cols,
+                                          dt(self.dtype16), stream()), "tfam_fold_layernorm")
+
     def _put_p(self, slot, layer, *vals):
         off = self._off(slot, layer)
         for v in vals:
@@ -86,20 +98,22 @@ class TfamPack:
         if self.pack_is_current():
             return self
         D, m = self.D, self.model
+        cross = m.use_cross_attention and not (m.use_only_rgb or m.use_only_flow)
         for i, layer in enumerate(m.layers):
             sa, ca = layer.self_attn, layer.cross_attn
-            self._put_w(W_SELF_IN, i, sa.in_proj_weight)
+            if i == 0:                                    # layer 0 reads the raw tokens: nothing to fold
+                self._put_w(W_SELF_IN, i, sa.in_proj_weight)
+                self._put_p(P_SELF_IN_B, i, sa.in_proj_bias)
+            else:
+                self._put_folded(W_SELF_IN, P_SELF_IN_B, i, sa.in_proj_weight, sa.in_proj_bias, m.layers[i - 1].norm_ffn)
             self._put_w(W_SELF_OUT, i, sa.out_proj.weight)
-            self._put_w(W_CROSS_Q, i, ca.in_proj_weight[:D])
+            self._put_folded(W_CROSS_Q, P_CROSS_Q_B, i, ca.in_proj_weight[:D], ca.in_proj_bias[:D], layer.norm_self)
             self._put_w(W_CROSS_OUT, i, ca.out_proj.weight)
-            self._put_w(W_FFN0, i, layer.ffn[0].weight)
+            self._put_folded(W_FFN0, P_FFN0_B, i, layer.ffn[0].weight, layer.ffn[0].bias, layer.norm_cross if cross else layer.norm_self)
             self._put_w(W_FFN3, i, layer.ffn[3].weight)
             self._put_w(W_KV_ALL, i, ca.in_proj_weight[D:])
-            self._put_p(P_SELF_IN_B, i, sa.in_proj_bias)
             self._put_p(P_SELF_OUT_B, i, sa.out_proj.bias)
-            self._put_p(P_CROSS_Q_B, i, ca.in_proj_bias[:D])
             self._put_p(P_CROSS_OUT_B, i, ca.out_proj.bias)
-            self._put_p(P_FFN0_B, i, layer.ffn[0].bias)
             self._put_p(P_FFN3_B, i, layer.ffn[3].bias)
             self._put_p(P_NORM_SELF, i, layer.norm_self.weight, layer.norm_self.bias)
             self._put_p(P_NORM_CROSS, i, layer.norm_cross.weight, layer.norm_cross.bias)
