@@ -270,8 +270,8 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
     if (p0 != wave * PB) tf_attn_load<DH, QT, NKT>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      if (p0 + i >= npairs) break;                 // wave-uniform
-      const int p = p0 + i;
+      const bool valid = p0 + i < npairs;           // no early exit: the PB chains are independent and get interleaved
+      const int p = min(p0 + i, npairs - 1);
       const int ci = p / a.H, h = p - ci * a.H;
       const uint32_t lb = ci ? f.livebits[1] : f.livebits[0];
 #pragma unroll
@@ -320,7 +320,7 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
         }
         const float inv = 1.0f / osum[0];
         const int arow = ci * a.T + 16 * qt + r;   // row of the A image
-        if (16 * qt + r < a.T) {
+        if (valid && 16 * qt + r < a.T) {
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const int col = h * DH + 16 * dt + 4 * q;
@@ -336,15 +336,18 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
 __device__ __forceinline__ uint32_t tf_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(const VMC_LDS char*)p; }
 
 // ---- epilogue: one lane's 4 consecutive columns of one row -------------------------------------------------------------
+// pre_added: bias (and residual) are already inside v (tf_gemm_body seeds the accumulators with them)
 template <typename T, int EPI>
-__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v) {
+__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v, bool pre_added = false) {
   if (col >= a.N) return;
   if (col + 3 < a.N) {
-    const float4 b = *(const float4*)(a.bias + col);
-    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    if (EPI == EPI_RESID32) {
-      const float4 rr = *(const float4*)(a.resid + (size_t)grow * a.ldres + col);
-      v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+    if (!pre_added) {
+      const float4 b = *(const float4*)(a.bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      if (EPI == EPI_RESID32) {
+        const float4 rr = *(const float4*)(a.resid + (size_t)grow * a.ldres + col);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      }
     }
     if (EPI == EPI_ACT16) {
       *(uint2*)((uint16_t*)a.out + (size_t)grow * a.ldo + col) =
@@ -392,7 +395,11 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
     tf_stage_w(a, w_img, n0, BN, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                             // V (and W) images complete
+#ifndef TF_SKIP_ATTN
     tf_pro_attn<T, DH, QT, NKT>(a, fr, a_img, v_img, rb, wave, lane);
+#else
+    asm volatile("" ::"v"(fr.kf[0][0][0].x), "v"(fr.qf[0][0][0].x), "v"(fr.livebits[0]));
+#endif
   } else {
     tf_stage_w(a, w_img, n0, BN, wave, lane);
     if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane);
@@ -408,6 +415,24 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
 #pragma unroll
   for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int arow = 16 * rt + r;
+  const int grow_e = rb * a.rpb + arow;
+  const bool store_e = ks == 0 && arow < a.rpb && grow_e < a.M;
+  if (store_e && a.N % 4 == 0) {
+    // the epilogue's bias (+ residual) operands ride under the MFMA loop: start the K-half-0 accumulators from them
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) {
+      const int col = n0 + 16 * n + 4 * q;
+      if (col < a.N) {
+        const float4 b = *(const float4*)(a.bias + col);
+        acc[n] = (f32x4){b.x, b.y, b.z, b.w};
+        if constexpr (EPI == EPI_RESID32) {
+          const float4 rr = *(const float4*)(a.resid + (size_t)grow_e * a.ldres + col);
+          acc[n] += (f32x4){rr.x, rr.y, rr.z, rr.w};
+        }
+      }
+    }
+  }
+  const bool pre_added = a.N % 4 == 0;
   const char* ap = a_img + arow * ROWB;
   constexpr int KB = KSTEPS % 4 == 0 ? 4 : (KSTEPS % 3 == 0 ? 3 : (KSTEPS % 2 == 0 ? 2 : 1));   // k-steps whose reads are batched
 #pragma unroll
@@ -439,7 +464,7 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
 #pragma unroll
       for (int n = 0; n < NTN; ++n) {
         const f32x4 o = *(const f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16);
-        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o);
+        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o, pre_added);
       }
     }
   }
@@ -451,13 +476,13 @@ __global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
   tf_gemm_body<T, BN, PRO, EPI, KD, DH, QT, NKT>(a, blockIdx.x, tf_smem);
 }
 
-// Two independent problems of the same kind in one launch (layer 0's qkv projection + the hoisted K|V projection of the
-// motion tokens: neither depends on the other, so the K|V GEMM costs no launch of its own).
+// Two independent problems in one launch: a layer's qkv projection (raw tokens or LayerNorm prologue) + the K|V projection of
+// the raw motion tokens for that layer's cross attention: neither depends on the other, so the K|V GEMM costs no launch of its own.
 template <typename T, int BN, int PRO, int EPI, int KD>
 __global__ void __launch_bounds__(TF_NTH) tf_gemm_pair_kernel(const TfArgs a, const TfArgs b, int blocks_a) {
   extern __shared__ __attribute__((aligned(16))) char tf_smem[];
   if ((int)blockIdx.x < blocks_a) tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1>(a, blockIdx.x, tf_smem);
-  else tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1>(b, blockIdx.x - blocks_a, tf_smem);
+  else tf_gemm_body<T, BN, PRO_F32, EPI, KD, 64, 1, 1>(b, blockIdx.x - blocks_a, tf_smem);      // b: always raw fp32 rows
 }
 
 // ---- chunked-K kernel (FFN second linear): A 16-bit and W both by LDS-DMA through an NST-deep ring -----------------------
@@ -872,12 +897,37 @@ int tf_kv_impl(const float* motion, const uint16_t* wp, const float* pp, const T
   return tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N, a.rpb, a.K, false), s);
 }
 
-// layer 0's qkv projection and the hoisted K|V projection in ONE launch (both read raw fp32 tokens, neither needs the other)
-template <typename T>
-int tf_qkv0_kv_pair(TfArgs& a, TfArgs& b, int bn, hipStream_t s) {
-#define TF_PAIR(BNV) (a.K == 768 ? tf_launch_pair<T, BNV, PRO_F32, EPI_ACT16, 768>(a, b, s) : tf_launch_pair<T, BNV, PRO_F32, EPI_ACT16, 512>(a, b, s))
+// a layer's qkv projection and its cross-attention K|V projection in ONE launch
+template <typename T, int PRO>
+int tf_qkv_kv_pair(TfArgs& a, TfArgs& b, int bn, hipStream_t s) {
+#define TF_PAIR(BNV) (a.K == 768 ? tf_launch_pair<T, BNV, PRO, EPI_ACT16, 768>(a, b, s) : tf_launch_pair<T, BNV, PRO, EPI_ACT16, 512>(a, b, s))
   TF_BN_SWITCH(bn, TF_PAIR)
 #undef TF_PAIR
+}
+
+// K|V of ONE layer (rows layer*2D.. of kv_all), written into that layer's columns of ws.kv
+inline TfArgs tf_kv_layer_args(const float* motion, const uint16_t* wp, const float* pp, int layer, const TfDims& d, const TfWs& w) {
+  TfArgs a = {};
+  a.A = motion; a.lda = d.D;
+  a.M = d.B * d.Tk; a.N = 2 * d.D; a.K = d.D; a.rpb = 32;
+  a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_KV_ALL, layer, d.D, d.ff, d.L, d.C); a.ldw = d.D;
+  a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, layer, d.D, d.ff, d.L, d.C);
+  a.out = w.kv + (size_t)layer * 2 * d.D; a.ldo = d.L * 2 * d.D; a.act = VMC_ACT_NONE;
+  return a;
+}
+
+// column tile of a paired launch: the widest that keeps both problems inside one resident round (1 workgroup per CU)
+inline int tf_pick_bn_pair(int Ma, int Na, int rpba, int Mb, int Nb, int K) {
+  const int cands[4] = {16, 32, 48, 64};
+  int best = 64;
+  for (int i = 0; i < 4; ++i) {
+    const int bn = cands[i];
+    if ((Na % bn) || (Nb % bn) || (size_t)(TF_BM + bn) * K * 2 + 8192 > TF_LDS_MAX) continue;
+    best = bn;
+    const long blocks = (long)(Na / bn) * ((Ma + rpba - 1) / rpba) + (long)(Nb / bn) * ((Mb + 31) / 32);
+    if (blocks <= 256) break;
+  }
+  return best;
 }
 
 // one AttentionLayer.  x_in: fp32 tokens of layer 0 (null for later layers: the input is then LN_ffn[layer-1](w.y)).
@@ -896,20 +946,21 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.M = M; a.N = 3 * D; a.K = D; a.rpb = rpb;
     a.W = W(VMC_TFAM_W_SELF_IN); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_IN_B, layer);
     a.out = w.qkv; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
-    const int bn = tf_pick_bn(M, a.N, rpb, D, false);
+    const bool pair = merge_kv_motion != nullptr && d.has_cross;
+    TfArgs b = {};
+    int bn = tf_pick_bn(M, a.N, rpb, D, false);
+    if (pair) {
+      b = tf_kv_layer_args(merge_kv_motion, wp, pp, layer, d, w);
+      bn = tf_pick_bn_pair(M, a.N, rpb, b.M, b.N, D);
+    }
     if (x_in != nullptr) {
       a.A = x_in; a.lda = D;
-      if (merge_kv_motion != nullptr) {
-        TfArgs b = tf_kv_args(merge_kv_motion, wp, pp, d, w);
-        rc = tf_qkv0_kv_pair<T>(a, b, bn, s);
-      } else {
-        rc = tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, bn, s);
-      }
+      rc = pair ? tf_qkv_kv_pair<T, PRO_F32>(a, b, bn, s) : tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, bn, s);
       resid = x_in;
     } else {
       a.A = w.y; a.lda = D; a.eps = 1e-5f;
       a.ln_g = P(VMC_TFAM_P_NORM_FFN, layer - 1); a.ln_b = a.ln_g + D; a.xout = w.xa;
-      rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, bn, s);
+      rc = pair ? tf_qkv_kv_pair<T, PRO_LN>(a, b, bn, s) : tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, bn, s);
       resid = w.xa;
     }
     if (rc) return rc;
@@ -1072,7 +1123,7 @@ extern "C" int vmc_tfam_forward(const float* x, const float* motion, const uint8
   hipStream_t s = (hipStream_t)stream;
   for (int l = 0; l < L; ++l) {
     const float* xin = l == 0 ? x : nullptr;
-    const float* mkv = (l == 0 && has_cross) ? motion : nullptr;     // the hoisted K|V GEMM rides layer 0's first launch
+    const float* mkv = has_cross ? motion : nullptr;     // each layer's K|V projection of the motion tokens rides its qkv launch
     const int rc = dtype16 == VMC_BF16 ? tf_layer_impl<BF16>(xin, mask, mask_kv, (const uint16_t*)wpack, ppack, l, d, w, s, mkv)
                                        : tf_layer_impl<F16>(xin, mask, mask_kv, (const uint16_t*)wpack, ppack, l, d, w, s, mkv);
     if (rc) return rc;
