@@ -8,6 +8,11 @@ data-path collective (weak scaling: 256 frames per rank per step).
 
     python bench.py [--gpus N --steps K --warmup W] [--model ViT-L/14 --frames 256 --dtype bf16]
 
+``--gpus N`` with no WORLD_SIZE in the environment starts the N ranks itself: the parent process (which never touches a
+GPU) spawns N children of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, relays
+rank 0's JSON line and exits non-zero if any rank fails.  Under ``python -m torch.distributed.run`` (WORLD_SIZE set) it is one
+of the ranks.  One rank per GPU, RCCL backend.
+
 Prints ONE JSON line on rank 0.  `roofline` is the MFMA roofline of the dominant kernel family (the
 vmc_linear GEMMs): algorithmic FLOPs of every GEMM launch of K instrumented steps divided by the HIP-event
 duration of exactly those launches.  `cpu_baseline` times the CPU oracle (oracle/vit.py, fp32 PyTorch) on a
@@ -47,6 +52,119 @@ def _time_cuda(fn, iters, warmup=3):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Parent of an N-rank run: no torch.cuda / HIP call happens in this process.  Children get the torchrun environment."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                                 # exact PID of a child this process started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return int(rc != 0)
+
+
+def all_ranks_ok(ok: bool, dev, world: int) -> bool:
+    """Agree across ranks before entering a leg's collectives: one rank's failed set-up must not leave the others hanging."""
+    if world == 1:
+        return ok
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def max_over_ranks(x: float, dev, world: int) -> float:
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _time_step_dist(step, iters, dev, world, warmup=3):
+    """barrier + synchronize on both sides of `iters` steps, MAX over ranks (the bench contract, for the secondary legs too)."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return max_over_ranks((time.perf_counter() - t0) / iters, dev, world)
+
+
+def student_train_leg(dev, rank, world, cdt, clips=32, T=16, name="ViT-B/32", iters=8):
+    """MoCLIP student distillation step (BASELINE.json configs[2]; train.py:89-107): per GPU 32 clips x 16 flow frames 224^2 u8,
+    forward + cosine distillation + BCE + backward with the gradient all-reduce (RCCL, 48 MB buckets issued during the
+    backward) + fused Adam; weak scaling (per-GPU batch fixed)."""
+    from vimo_clip_amd import synth
+    from vimo_clip_amd.losses import classification_loss, distillation_loss
+    from vimo_clip_amd.models import FlowStudentModel
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    from vimo_clip_amd.parallel import GradientAllReducer, broadcast_parameters
+
+    ok, err = True, ""
+    try:
+        E = synth.VIT_GEOMETRY[name][5]
+        m = FlowStudentModel(name, device=str(dev), num_classes=140, compute_dtype=cdt).train()
+        m.load_state_dict(synth.student_state_dict(name, 3, zero_fc2=True), strict=True)
+        arena = GradArena(m.parameters())
+        vids = synth.randint_u8(3 + rank, "vids", (clips, T, 3, 224, 224)).to(dev)
+        teacher = synth.normal(3 + rank, "teacher", (clips, T + 1, E)).to(dev)
+        labels = synth.multi_hot_labels(3 + rank, "labels", clips, 140).to(dev)
+    except Exception as e:      # noqa: BLE001
+        ok, err = False, f"{type(e).__name__}: {e}"
+    if not all_ranks_ok(ok, dev, world):
+        return {"error": err or "set-up failed on another rank"}
+    broadcast_parameters(arena.flat_param)
+    opt = FusedAdam(arena, lr=1e-3)
+    red = GradientAllReducer(arena.flat_grad).attach(arena)
+
+    def step():
+        emb, emb_d, logits = m(vids)
+        loss = distillation_loss(emb_d, teacher[:, :-1, :], mode="cosine") + classification_loss(logits, labels, positive_weight=9)
+        loss.backward()
+        opt.step(grad_scale=red.all_reduce())
+
+    t = _time_step_dist(step, iters, dev, world, warmup=2)
+    red.detach()                                     # the hook list is global: this leg's reducer must not see the next leg's backward
+    frames = clips * T
+    fwd = vit_flops_per_frame(name)
+    from vimo_clip_amd.synth import VIT_GEOMETRY
+    R, p, D = VIT_GEOMETRY[name][0], VIT_GEOMETRY[name][1], VIT_GEOMETRY[name][2]
+    step_flops = 3 * fwd - 2 * ((R // p) ** 2) * 3 * p * p * D        # SURVEY 8d: no input dgrad of the patch GEMM
+    return {"model": name, "clips_per_gpu": clips, "frames_per_clip": T, "ms_per_step": round(1e3 * t, 3),
+            "frames_per_s": round(frames * world / t, 1), "grad_allreduce_bytes": arena.numel * 4,
+            "mfma_frac": round(frames / t * step_flops / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            "note": "fwd + bwd + overlapped gradient all-reduce + fused Adam; whole job frames/s over all ranks"}
 
 
 def tfam_hbm_bytes(B, T=16, Tk=16, D=768, ff=2048, L=4, C=140, e_w=2):
@@ -122,63 +240,53 @@ def tfam_forward_block(dev, rank, cdt, batches=(8, 16, 64), iters=200):
 
 def tfam_extras(dev, rank, world, cdt):
     """TFAM (BASELINE.json configs[3]): d_model 768, 8 heads, 4 layers, ff 2048, 16x768 RGB + motion tokens,
-    cross-attention.  Forward clips/s at small and large batch; full train step (fwd + bwd + gradient all-reduce
-    over RCCL when world > 1 + fused AdamW) with the HBM roofline of the AdamW kernel (28 B/parameter)."""
-    import torch.distributed as dist
-
+    cross-attention.  Large-batch forward clips/s (MFMA regime; single GPU only) and the full train step (fwd + bwd +
+    gradient all-reduce over RCCL when world > 1 + fused AdamW) with the HBM roofline of the AdamW kernel (28 B/parameter)."""
     from vimo_clip_amd import synth
     from vimo_clip_amd.losses import bce_with_logits_loss
     from vimo_clip_amd.optim import FusedAdam, GradArena
     from vimo_clip_amd.parallel import GradientAllReducer, broadcast_parameters
     from vimo_clip_amd.TFAM.models import AMO_CLIP
 
-    out = {}
-    m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0,
-                 device=dev, compute_dtype=cdt).to(dev)
-    m.load_state_dict(synth.tfam_state_dict(768, 8, 4, 2048, 140, 4), strict=True)
+    out, ok, err = {}, True, ""
     flops_clip = 1.0136e9
-    for B in (8, 512, 4096):
-        rgb = synth.normal(10 + rank, f"rgb{B}", (B, 16, 768)).to(dev)
-        mot = synth.normal(10 + rank, f"mot{B}", (B, 16, 768)).to(dev)
-        mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
-        m.eval()
-        with torch.no_grad():
-            t = _time_cuda(lambda: m(rgb, mot, mask_rgb=mk, mask_flow=mk), 20 if B <= 512 else 5)
-        out[f"tfam_fwd_clips_per_s_B{B}"] = round(B / t, 1)
-        out[f"tfam_fwd_mfma_frac_B{B}"] = round(B / t * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)
-        if B == 8:   # the reference's batch size: launch-bound, so also as ONE hipGraph replay per forward
-            from vimo_clip_amd.graphs import GraphedCallable
-
-            def fwd(r, f, a, b):
-                with torch.no_grad():
-                    return m(r, f, mask_rgb=a, mask_flow=b)
-            g = GraphedCallable(fwd, rgb, mot, mk, mk)
-            t = _time_cuda(g.replay, 50)
-            out["tfam_fwd_clips_per_s_B8_hipgraph"] = round(B / t, 1)
-            # HBM roofline of the small-batch forward: bf16 weights 63.7 MB + 98 KB/clip of fp32 tokens (SURVEY.md 8d)
-            out["tfam_fwd_hbm_frac_B8_hipgraph"] = round((63.7e6 + B * 98304) / t / 8e12, 4)
-    # ---- train step, per-GPU batch 512 (weak scaling), AdamW lr 1e-4 wd 0.1 as TFAM/train_and_eval.py:53 ----
     B = 512
-    m.train()
-    arena = GradArena(m.used_parameters())
+    try:
+        m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0,
+                     device=dev, compute_dtype=cdt).to(dev)
+        m.load_state_dict(synth.tfam_state_dict(768, 8, 4, 2048, 140, 4), strict=True)
+        if world == 1:
+            for Bf in (512, 4096):
+                rgb = synth.normal(10 + rank, f"rgb{Bf}", (Bf, 16, 768)).to(dev)
+                mot = synth.normal(10 + rank, f"mot{Bf}", (Bf, 16, 768)).to(dev)
+                mk = torch.ones(Bf, 16, dtype=torch.bool, device=dev)
+                m.eval()
+                with torch.no_grad():
+                    t = _time_cuda(lambda: m(rgb, mot, mask_rgb=mk, mask_flow=mk), 20 if Bf <= 512 else 5)
+                out[f"tfam_fwd_clips_per_s_B{Bf}"] = round(Bf / t, 1)
+                out[f"tfam_fwd_mfma_frac_B{Bf}"] = round(Bf / t * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)
+        # ---- train step, per-GPU batch 512 (weak scaling), AdamW lr 1e-4 wd 0.1 as TFAM/train_and_eval.py:53 ----
+        m.train()
+        arena = GradArena(m.used_parameters())
+        rgb = synth.normal(20 + rank, "rgb_t", (B, 16, 768)).to(dev)
+        mot = synth.normal(20 + rank, "mot_t", (B, 16, 768)).to(dev)
+        mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
+        y = synth.multi_hot_labels(20 + rank, "lab_t", B, 140).to(dev)
+    except Exception as e:      # noqa: BLE001
+        ok, err = False, f"{type(e).__name__}: {e}"
+    if not all_ranks_ok(ok, dev, world):
+        return {"error": err or "set-up failed on another rank"}
     broadcast_parameters(arena.flat_param)
     opt = FusedAdam(arena, lr=1e-4, weight_decay=0.1, decoupled=True)
     red = GradientAllReducer(arena.flat_grad).attach(arena)      # bucket all-reduces overlap the backward (N > 1)
-    rgb = synth.normal(20 + rank, "rgb_t", (B, 16, 768)).to(dev)
-    mot = synth.normal(20 + rank, "mot_t", (B, 16, 768)).to(dev)
-    mk = torch.ones(B, 16, dtype=torch.bool, device=dev)
-    y = synth.multi_hot_labels(20 + rank, "lab_t", B, 140).to(dev)
 
     def train_step():
         loss = bce_with_logits_loss(m(rgb, mot, mask_rgb=mk, mask_flow=mk), y)
         loss.backward()
         opt.step(grad_scale=red.all_reduce())
 
-    t = _time_cuda(train_step, 10)
-    if world > 1:
-        tt = torch.tensor([t], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
+    t = _time_step_dist(train_step, 10, dev, world)
+    red.detach()
     out["tfam_train_clips_per_s"] = round(B * world / t, 1)          # whole job, per-GPU batch 512 (weak scaling)
     out["tfam_train_per_gpu_batch"] = B
     out["tfam_train_ms_per_step"] = round(1e3 * t, 3)
@@ -200,6 +308,24 @@ def tfam_extras(dev, rank, world, cdt):
     return out
 
 
+def selftest_spawn(rank: int, world: int) -> None:
+    """CPU rehearsal of the N-rank control flow (tests/test_bench_spawn.py): gloo rendezvous from the spawned environment,
+    one all-reduce, rank 0 prints a line in the bench format.  No GPU is touched."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": float(t.item()), "n_gpus": world, "ranks_sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if os.environ.get("VMC_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(3)                                  # the parent must report a failing rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,13 +338,20 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the TFAM measurements")
     ap.add_argument("--no-fuse-add-ln", action="store_true", help="A/B: residual add in the GEMM epilogue + plain LayerNorm")
+    ap.add_argument("--selftest-spawn", action="store_true", help="CPU/gloo rehearsal of the --gpus N spawn path (tests)")
     ap.add_argument("--only", default="", choices=["", "tfam"], help="builder shortcut: run one secondary leg alone and print it")
     ap.add_argument("--chunk", type=int, default=0, help="frames per encoder pass inside a step (0 = all frames of the step at once)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's command form `python bench.py --gpus N`: start the N ranks here, before anything touches a GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.selftest_spawn:
+        selftest_spawn(rank, world)
+        return
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -292,11 +425,23 @@ def main():
         "end_to_end_mfma_frac": round(fps / world * flops_frame / (MFMA_PEAK_TFLOPS * 1e12), 4),
     }
 
-    # secondary measurements never take the headline down with them: a failure is reported inside the JSON line
-    try:
-        result["extras"] = {} if args.no_extras else tfam_extras(dev, rank, world, cdt)
-    except Exception as e:      # noqa: BLE001
-        result["extras"] = {"error": f"{type(e).__name__}: {e}"}
+    # secondary measurements never take the headline down with them: a failure is reported inside the JSON line, and every
+    # leg with collectives agrees on its set-up across ranks before it enters them (all_ranks_ok)
+    if not args.no_extras:
+        def guarded(leg):
+            if world > 1:
+                return leg()                        # a rank that dies takes the job down (the parent reports it); no silent hang
+            try:
+                return leg()
+            except Exception as e:      # noqa: BLE001
+                return {"error": f"{type(e).__name__}: {e}"}
+        result["student_train"] = guarded(lambda: student_train_leg(dev, rank, world, cdt))        # BASELINE.json configs[2]
+        result["extras"] = guarded(lambda: tfam_extras(dev, rank, world, cdt))                     # configs[3], train step
+        if world == 1:
+            try:
+                result["tfam_forward"] = tfam_forward_block(dev, rank, cdt)        # configs[3], small-batch forward vs HBM roofline
+            except Exception as e:      # noqa: BLE001
+                result["tfam_forward"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         try:

@@ -100,14 +100,18 @@ def test_fused_chain_vs_oracle_over_batch_sizes(B, dtype):
     """Cross mode at the BASELINE geometry (D 768, H 8, ff 2048, L 4, T 16 / Tk 15) with ragged masks, batches that do and
     do not fill the 2-clip row blocks, against the CPU oracle (pinned to the reference by tests/golden/tfam.npz)."""
     c = dict(name=f"b{B}", D=768, H=8, L=4, ff=2048, C=140, B=B, Tr=16, Tf=15, mode="cross", pe=False, ragged=True, seed=900 + B)
+    from vimo_clip_amd import tfam_fused as tf
     m = _tfam(c, dtype)
     rgb, mot, mr, mf = mg.tfam_inputs(c)
-    with torch.no_grad():
-        y = m(rgb.cuda(), mot.cuda(), mask_rgb=mr.cuda(), mask_flow=mf.cuda()).cpu()
+    # straight through the C ABI (AMO_CLIP.forward itself hands batches above tfam_fused.MAX_ROWS rows to the per-op path)
+    pack = tf.get_pack(m, dtype).refresh()
+    y = pack.forward(rgb.cuda().contiguous(), mot.cuda().contiguous(), mr.cuda().to(torch.uint8).contiguous(),
+                     mf.cuda().to(torch.uint8).contiguous(), True).cpu()
     sd = synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"])
     ref = otfam.amo_clip_forward(sd, rgb, mot, mr, mf, nhead=8)
     err = (y - ref).abs().max().item()
     print(f"fused B={B} {dtype}: max abs err {err:.3e} (|ref|max {ref.abs().max():.2f})")
+    assert tf.supported(m, B, 16, 15, True) == (B * 16 <= tf.MAX_ROWS)
     assert err <= TOL[dtype] * max(1.0, ref.abs().max().item())
 
 

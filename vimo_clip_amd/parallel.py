@@ -69,10 +69,12 @@ class GradientAllReducer:
     # ---- overlap with the backward ------------------------------------------------------------------
     def attach(self, arena, register: bool = True):
         """arena: optim.GradArena (``params`` + ``offsets`` into the flat gradient buffer)."""
-        self._pbuckets = {}
+        import weakref
+        self._pbuckets, self._prefs = {}, {}
         for p, o in zip(arena.params, arena.offsets):
             b0, b1 = o // self.bucket_elems, (o + max(1, p.numel()) - 1) // self.bucket_elems
             self._pbuckets[id(p)] = list(range(b0, b1 + 1))
+            self._prefs[id(p)] = weakref.ref(p)     # id() values are recycled once a parameter dies
         self._expected = None                      # id(param) -> reports per backward, learned in the first step
         self._counts = {}
         self._launched = [False] * len(self.buckets)
@@ -95,7 +97,7 @@ class GradientAllReducer:
 
     def on_grad_ready(self, param):
         k = id(param)
-        if not self._attached or world_size() == 1 or k not in self._pbuckets:
+        if not self._attached or world_size() == 1 or k not in self._pbuckets or self._prefs[k]() is not param:
             return
         self._counts[k] = self._counts.get(k, 0) + 1
         if self._expected is None or self._counts[k] != self._expected.get(k, 0):

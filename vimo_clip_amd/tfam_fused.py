@@ -25,6 +25,7 @@ W_SELF_IN, W_SELF_OUT, W_CROSS_Q, W_CROSS_OUT, W_FFN0, W_FFN3, W_KV_ALL, W_CLS1,
  P_KV_ALL_B, P_CLS_LN, P_CLS1_B, P_CLS4_B, P_END) = range(16, 30)
 
 MAX_T = 32
+MAX_ROWS = 256      # B*T above which the per-op path (256x256 GEMM tiles) wins: measured crossover B = 16 at T = 16 (profiles/README.md)
 
 
 def supported(model, B, T, Tk, has_cross) -> bool:
@@ -33,7 +34,7 @@ def supported(model, B, T, Tk, has_cross) -> bool:
     ff = model.layers[0].ffn[0].weight.shape[0]
     if D not in (512, 768) or D % H or D // H not in (64, 96):
         return False
-    if not 0 < T <= MAX_T or (has_cross and not 0 < Tk <= MAX_T) or ff % 512:
+    if not 0 < T <= MAX_T or (has_cross and not 0 < Tk <= MAX_T) or ff % 512 or B * T > MAX_ROWS:
         return False
     if ((2 if T <= 16 else 1) * H) % 4:
         return False
