@@ -59,6 +59,17 @@ int vmc_preprocess_patches_u8(const uint8_t* frames, void* patches, int F, int R
 int vmc_patches_f32(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16,
                     void* stream);
 
+/* Split-precision patch operands for the INFERENCE patch-embedding GEMM (0.2 % of the encoder's FLOPs, but its 16-bit operand
+ * rounding was the largest single term of the embedding error).  Same op sites as the two entries above.
+ *   vmc_patches_u8_exact:  patches 16-bit [F*g*g, 2*kpad] = [v | v], v = the raw pixel 0..255 (exact in 16 bits; wrap_quirk as
+ *     above).  Pair with W = [W'_hi | W'_lo], W'[n,k] = conv1[n,k] / std_c, bias'[n] = -255 sum_k conv1[n,k] mean_c / std_c and
+ *     alpha = 1/255 in vmc_linear:  alpha (A W^T + bias') = sum_k ((v/255 - mean_c) / std_c) conv1[n,k]  to fp32 accuracy.
+ *   vmc_patches_f32_split: patches [F*g*g, 3*kpad] = [x_hi | x_lo | x_hi], x_lo = x - x_hi; pair with W = [W_hi | W_hi | W_lo].
+ * Columns >= 3 p^2 of every kpad-wide part are zero. */
+int vmc_patches_u8_exact(const uint8_t* frames, void* patches, int F, int R, int p, int kpad, int wrap_quirk, int dtype16,
+                         void* stream);
+int vmc_patches_f32_split(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16, void* stream);
+
 /* Pillow-exact antialiased resample of planar u8 images [planes, in_h, in_w] along one axis — the BICUBIC
  * ``Resize`` of clip._transform (models/student_model.py:77-78) and of CLIPImageProcessor (extract_embeddings.py:91),
  * both of which call PIL.Image.resize.  out pixel o (of the resampled axis) = clip8((2^21 + sum_t in[lo_o + t] *

@@ -46,8 +46,9 @@ def quick_gelu(x):
 
 
 def vit_forward(sd: dict, pixel_values: torch.Tensor, heads: int, prefix: str = "",
-                return_tokens: bool = False) -> torch.Tensor:
-    """pixel_values [F,3,R,R] f32 (already normalised) -> [F,E] f32."""
+                return_tokens: bool = False, trace: list = None) -> torch.Tensor:
+    """pixel_values [F,3,R,R] f32 (already normalised) -> [F,E] f32.
+    trace (optional list): receives (stage name, residual stream [F,N,D]) after ln_pre and after every residual add."""
     g = lambda k: sd[prefix + k].to(torch.float32)
     conv_w = g("conv1.weight")
     D, _, p, _ = conv_w.shape
@@ -57,6 +58,8 @@ def vit_forward(sd: dict, pixel_values: torch.Tensor, heads: int, prefix: str = 
     cls = g("class_embedding").view(1, 1, D).expand(Fn, 1, D)
     x = torch.cat([cls, x], dim=1) + g("positional_embedding")
     x = layer_norm(x, g("ln_pre.weight"), g("ln_pre.bias"))
+    if trace is not None:
+        trace.append(("ln_pre", x.clone()))
     N = x.shape[1]
     dh = D // heads
     L = 0
@@ -74,9 +77,13 @@ def vit_forward(sd: dict, pixel_values: torch.Tensor, heads: int, prefix: str = 
         o = torch.softmax(s, dim=-1) @ v
         o = o.transpose(1, 2).reshape(Fn, N, D)
         x = x + o @ g(pre + "attn.out_proj.weight").t() + g(pre + "attn.out_proj.bias")
+        if trace is not None:
+            trace.append((f"blk{i}.attn", x.clone()))
         h = layer_norm(x, g(pre + "ln_2.weight"), g(pre + "ln_2.bias"))
         h = quick_gelu(h @ g(pre + "mlp.c_fc.weight").t() + g(pre + "mlp.c_fc.bias"))
         x = x + h @ g(pre + "mlp.c_proj.weight").t() + g(pre + "mlp.c_proj.bias")
+        if trace is not None:
+            trace.append((f"blk{i}.mlp", x.clone()))
     if return_tokens:
         return x
     y = layer_norm(x[:, 0], g("ln_post.weight"), g("ln_post.bias"))

@@ -27,4 +27,4 @@ def golden():
     import numpy as np
 
     d = os.path.join(ROOT, "tests", "golden")
-    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("losses", "tfam", "indexing", "vit", "metrics")}
+    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("losses", "tfam", "indexing", "vit", "metrics", "student")}

@@ -1,13 +1,18 @@
 """GPU: CLIP ViT encoder (HIP path through the C ABI) vs the CPU oracle and the golden fixtures that
 oracle/make_golden.py recorded from transformers.CLIPModel.
 
-Tolerances (BASELINE.json north_star: "CLIP embeddings ... within 1e-3 fp16"):
-  f16 compute, fp32 residual stream : |y - y_ref| <= 1e-3 * max(1, max|y_ref|)   (the stated 1e-3)
-  bf16 compute (the bench dtype)    : 8x looser (bf16 has 3 fewer mantissa bits than f16): 8e-3
-  "stress" fixtures (weight scales x2, i.e. attention logits x4; tiny14) get the bound x stress^2: they exist
-  to show the error stays proportional under large-norm activations, not to meet the nominal bound.
-Measured on MI355X (gpurun, round 1): f16 1.0e-3..1.5e-3 absolute on |y|max 3.1..3.9 (3e-4..5e-4 relative);
-bf16 0.9e-2..1.2e-2 absolute (3e-3 relative).
+Tolerances (BASELINE.json north_star: "CLIP embeddings ... within 1e-3 fp16"), read as fp16-level RELATIVE accuracy:
+  f16 compute, fp32 residual stream : |y - y_ref| <= 1e-3 * max(1, max|y_ref|)   -- the dtype that carries the 1e-3 claim
+  bf16 compute (the bench dtype)    : 8x looser (bf16 has 3 fewer mantissa bits than f16): 8e-3, same scaling
+Measured on MI355X (round 2): f16 1.1e-3..1.5e-3 ABSOLUTE on |y|max 3.1..3.9, i.e. 3.5e-4..4.5e-4 relative; bf16 0.9e-2..1.2e-2
+absolute (3e-3 relative).  A plain absolute 1e-3 is not met by 16-bit MFMA operands on 24 layers: test_per_stage_error_trace
+shows where the error comes from -- every block injects ~0.75..1 x eps16 x |branch| (the 16-bit roundings of its GEMM operands
+h, qkv, P, o, u), the contributions add like a random walk, the patch embedding adds nothing (split-precision operands,
+vmc_patches_u8_exact) and an fp32 branch tensor changes the result by 1 % (measured: 1.355e-3 vs 1.368e-3, ViT-L/14 f16).
+"stress" fixtures (weight scales x s = 2; tiny14) get the bound x s^2: scaling every weight by s multiplies the q.k logits and
+each branch's output, relative to its unit-variance LayerNorm input, by s^2, and the per-block injected rounding noise is
+proportional to the branch magnitude (asserted per block by test_per_stage_error_trace: ISO x eps16 x branch scale), so the
+final error scales by s^2 -- measured 6.7e-3 (f16) against 4 x 1.4e-3.
 """
 import numpy as np
 import pytest
@@ -41,6 +46,13 @@ def test_encoder_vs_golden(golden, c, dtype):
     print(f"{c['name']} {dtype}: max abs err {err:.3e} / {err2:.3e}, scale {scale:.2f}")
     tol = TOL[dtype] * c["stress"] ** 2
     assert err <= tol * scale and err2 <= tol * scale
+    if c["name"] in ("l14", "tiny14"):
+        # the precise variant: residual adds in fp32 inside the GEMM epilogues (no 16-bit branch tensor), exact patch embedding
+        m.fuse_add_ln = False
+        y3 = m.encode_frames_u8(u8.cuda()).cpu()
+        m.fuse_add_ln, m.exact_patch_embed = True, False
+        y4 = m.encode_frames_u8(u8.cuda()).cpu()
+        print(f"   {c['name']} {dtype}: fp32-branch variant {(y3 - ref).abs().max().item():.3e}; 16-bit patch operands {(y4 - ref).abs().max().item():.3e}")
 
 
 def test_encoder_vs_oracle_fresh_seed():
@@ -123,3 +135,65 @@ def test_full_size_workload_properties_vit_l14():
     ref = ovit.vit_forward(sd, ovit.normalize_u8(u8[pick].cpu()), 16)
     err = (full[pick].cpu() - ref).abs().max().item()
     assert err <= TOL[torch.bfloat16] * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("name,stress", [("tiny14", 2.0), ("b32", 1.0), ("l14", 1.0)])
+def test_per_stage_error_trace(name, stress):
+    """VERDICT r1 'no per-stage error budget': the residual stream of the HIP encoder against the oracle's after ln_pre and
+    after every residual add, plus each block run ALONE on the oracle's exact input (isolates one block's roundings from what
+    it inherits).  Findings are printed (-s) and asserted as a budget:
+      * an isolated block adds at most ISO x eps16 x (branch scale) to the stream, eps16 = 2^-11 (f16) / 2^-8 (bf16): the 16-bit
+        roundings of h, qkv, P, o, u and of the branch itself are the whole error, nothing else leaks in;
+      * the end-to-end stream error is no more than the sum of the isolated block errors times AMP (errors add; LayerNorm and
+        the next block do not amplify them beyond that).
+    """
+    from vimo_clip_amd import ops
+    c = next(x for x in mg.VIT_CASES if x["name"] == name)
+    sd = synth.vit_state_dict(c["model"], c["seed"], c["stress"])
+    H = synth.VIT_GEOMETRY[c["model"]][4]
+    u8 = mg.vit_pixels(c)[:2]
+    ref_trace = []
+    ovit.vit_forward(sd, ovit.normalize_u8(u8), H, trace=ref_trace)
+    ISO, AMP = 6.0, 2.0
+    for dtype, eps in ((torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8)):
+        m = _encoder(c, dtype)
+        tr = []
+        patches = ops.patches_u8_exact(u8.cuda(), m.patch_size, dtype, False)
+        m._encode_patches(patches, u8.shape[0], trace=tr, patch_mode="u8_exact")
+        ref = dict(ref_trace)
+        rows = []
+        for stage, x in tr:
+            r = ref[stage].reshape(x.shape)
+            rows.append((stage, (x.cpu() - r).abs().max().item(), r.abs().max().item()))
+        # isolated blocks: exact (oracle) input -> one block of the shipped fused path
+        iso_sum, worst = 0.0, ("", 0.0)
+        stages = [s for s, _ in ref_trace]
+        for i, blk in enumerate(m.transformer.resblocks):
+            if f"blk{i}.mlp" not in ref:
+                break
+            x_in = ref[stages[stages.index(f"blk{i}.attn") - 1]].reshape(-1, m.width).cuda().contiguous()
+            Fn, N = u8.shape[0], x_in.shape[0] // u8.shape[0]
+            pre = f"blk{i}."
+            h, *_ = ops.layernorm(x_in, blk.ln_1.weight, blk.ln_1.bias, dtype)
+            qkv = ops.linear(h, m.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
+            o, _ = ops.attention_vit(qkv, Fn, N, m.heads)
+            a = ops.linear(o, m.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)
+            x1 = x_in + a.float()
+            e_attn = (x1.cpu() - ref[f"blk{i}.attn"].reshape(x1.shape)).abs().max().item()
+            x1e = ref[f"blk{i}.attn"].reshape(-1, m.width).cuda().contiguous()
+            h2, *_ = ops.layernorm(x1e, blk.ln_2.weight, blk.ln_2.bias, dtype)
+            u = ops.linear(h2, m.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+            mm = ops.linear(u, m.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias)
+            x2 = x1e + mm.float()
+            e_mlp = (x2.cpu() - ref[f"blk{i}.mlp"].reshape(x2.shape)).abs().max().item()
+            s_attn, s_mlp = a.float().abs().max().item(), mm.float().abs().max().item()
+            iso_sum += e_attn + e_mlp
+            for tag, e, sc in ((f"blk{i}.attn", e_attn, s_attn), (f"blk{i}.mlp", e_mlp, s_mlp)):
+                assert e <= ISO * eps * max(1.0, sc), (tag, dtype, e, sc)
+                if e / max(1.0, sc) > worst[1]:
+                    worst = (tag, e / max(1.0, sc))
+        final_stage, final_err, final_scale = rows[-1]
+        print(f"{name} {dtype}: " + "  ".join(f"{s}:{e:.1e}/{sc:.1f}" for s, e, sc in rows[:3] + rows[-2:]))
+        print(f"   isolated-block error sum {iso_sum:.2e}; end-to-end stream error {final_err:.2e} at |x|max {final_scale:.1f}; "
+              f"largest isolated error relative to its branch: {worst[0]} {worst[1] / eps:.2f} eps16")
+        assert final_err <= AMP * iso_sum + ISO * eps * final_scale, (name, dtype, final_err, iso_sum)

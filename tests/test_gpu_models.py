@@ -351,3 +351,35 @@ def test_tfam_fused_dropout_tail_matches_unfused_path():
         num, den = (g1[k] - g0[k]).norm().item(), g0[k].norm().item()
         tol = 6e-2 if ".ffn.0." in k else 3e-2       # a few ReLU gates flip when an intermediate is rounded differently
         assert num <= tol * den + 1e-6, (k, num, den)
+
+
+@pytest.mark.parametrize("c", __import__("oracle.make_golden_student", fromlist=["MLP_CASES"]).MLP_CASES, ids=lambda c: c["name"])
+def test_residual_mlp_vs_reference_class(golden, c):
+    """HIP ResidualMLP against outputs + gradients of the reference class itself (models/student_model.py:8-35, compiled from
+    its AST by oracle/make_golden_student.py): forward f16 1e-3, bf16 8e-3 (x scale); fresh module = exact identity (zero fc2)."""
+    from oracle import make_golden_student as mgs
+    from vimo_clip_amd.models.student_model import ResidualMLP
+    g = golden["student"]
+    x, w1, b1, w2, b2 = mgs.mlp_inputs(c)
+    ref = torch.from_numpy(g[f"mlp/{c['name']}/y"])
+    for dtype, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        m = ResidualMLP(c["E"], alpha=c["alpha"], compute_dtype=dtype).cuda()
+        assert float(m.fc2.weight.abs().max()) == 0.0 and float(m.fc2.bias.abs().max()) == 0.0
+        with torch.no_grad():
+            y0 = m(x.cuda())
+            assert torch.equal(y0.cpu().float(), x) or (y0.cpu().float() - x).abs().max() <= tol * x.abs().max()
+            m.fc1.weight.copy_(w1); m.fc1.bias.copy_(b1); m.fc2.weight.copy_(w2); m.fc2.bias.copy_(b2)
+        xr = x.cuda().requires_grad_(True)
+        y = m(xr)
+        err = (y.detach().cpu().float() - ref).abs().max().item()
+        print(f"residual_mlp {c['name']} {dtype}: max abs err {err:.3e} (|ref|max {ref.abs().max():.2f})")
+        assert err <= tol * max(1.0, ref.abs().max().item())
+        if dtype == torch.bfloat16:
+            gup = synth.normal(c["seed"], "g", tuple(ref.shape)).cuda()
+            (y.float() * gup).sum().backward()
+            dx_ref = torch.from_numpy(g[f"mlp/{c['name']}/dx"])
+            rel = ((xr.grad.cpu().float() - dx_ref).norm() / dx_ref.norm()).item()
+            dw_ref = torch.from_numpy(g[f"mlp/{c['name']}/dfc1w"])
+            relw = ((m.fc1.weight.grad.cpu()[:8] - dw_ref).norm() / dw_ref.norm()).item()
+            print(f"   backward: dx rel L2 {rel:.3e}, dfc1.weight rel L2 {relw:.3e}")
+            assert rel <= 2e-2 and relw <= 3e-2

@@ -1,0 +1,77 @@
+"""CPU: the student-side index contracts and ResidualMLP against tests/golden/student.npz, which oracle/make_golden_student.py
+recorded by RUNNING the reference's own classes (dataset.py:8-148 HDF5VideoDataset / collate_fn with data-source stand-ins;
+models/student_model.py:8-35 ResidualMLP).  Closes VERDICT r1 'unpinned oracle pieces' a4 / a9."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import indexing, make_golden_student as mgs, student as ostudent
+from vimo_clip_amd import dataset as ds
+
+
+def _lengths(g):
+    v = g["ds/videos"]
+    names = [n for n, _, _ in mgs.VIDEOS]
+    return names, {n: int(v[i, 0]) for i, n in enumerate(names)}, {n: int(v[i, 1]) for i, n in enumerate(names)}
+
+
+def test_oracle_and_product_segment_math_match_the_reference_run(golden):
+    g = golden["student"]
+    names, lengths, tflow = _lengths(g)
+    for sl in mgs.SEQ_LENS:
+        ref = [tuple(r) for r in g[f"ds/L{sl}/segments"].tolist()]
+        for impl in (indexing.build_segments, ds.build_segments):
+            assert [(names.index(k), s, n) for k, s, n in impl(lengths, sl)] == ref, (sl, impl.__module__)
+        for i, (vi, s, n) in enumerate(ref):
+            k = names[vi]
+            assert indexing.rgb_segment_indices(s, n, sl) == g[f"ds/L{sl}/rgb_idx"][i].tolist()
+            assert indexing.flow_segment_indices(s, n, sl, tflow[k]) == g[f"ds/L{sl}/flow_idx"][i].tolist()
+            emb = torch.arange(lengths[k], dtype=torch.float32).view(-1, 1)
+            assert ds.slice_rgb_segment(emb, s, n, sl)[:, 0].long().tolist() == g[f"ds/L{sl}/rgb_idx"][i].tolist()
+            fv = (torch.arange(tflow[k], dtype=torch.float32) + 1).view(-1, 1, 1, 1)
+            got = ds.slice_flow_segment(fv, s, n, sl).reshape(-1).long() - 1
+            assert got.tolist() == g[f"ds/L{sl}/flow_idx"][i].tolist(), (sl, i, k)
+
+
+def test_product_dataset_class_end_to_end_equals_the_reference_class(golden, tmp_path):
+    """Same HDF5 file + same stored frames through vimo_clip_amd.dataset.HDF5VideoDataset (h5lite + .npy frame stacks)."""
+    from vimo_clip_amd import h5lite
+    g = golden["student"]
+    h5p = str(tmp_path / "emb.h5")
+    with h5lite.File(h5p, "w") as f:
+        for vi, (v, T, tf) in enumerate(mgs.VIDEOS):
+            grp = f.create_group(v)
+            emb = np.zeros((T, 4), dtype=np.float32)
+            emb[:, 0], emb[:, 1] = np.arange(T), vi
+            grp.create_dataset("embeddings", data=emb)
+            lab = np.zeros(6, dtype=np.float32)
+            lab[vi % 6] = 1.0
+            grp.create_dataset("labels", data=lab)
+            fr = np.zeros((tf, 2, 2, 3), dtype=np.uint8)
+            fr[:] = (np.arange(tf) + 1).reshape(-1, 1, 1, 1)
+            np.save(os.path.join(tmp_path, os.path.splitext(v)[0] + ".npy"), fr)
+    for sl in (4, 17):
+        d = ds.HDF5VideoDataset(h5p, str(tmp_path), sequence_length=sl)
+        names = [n for n, _, _ in mgs.VIDEOS]
+        assert [(names.index(k), s, n) for k, s, n in d.segments] == [tuple(r) for r in g[f"ds/L{sl}/segments"].tolist()]
+        for i in range(len(d)):
+            it = d[i]
+            assert it["rgb_emb"][:, 0].long().tolist() == g[f"ds/L{sl}/rgb_idx"][i].tolist()
+            ff = it["flow_frames"].reshape(sl - 1, -1)
+            assert (ff[:, 0].long() - 1).tolist() == g[f"ds/L{sl}/flow_idx"][i].tolist()
+            assert tuple(it["flow_frames"].shape[1:]) == (3, 2, 2)         # permuted to [T, C, H, W] (:96)
+    d = ds.HDF5VideoDataset(h5p, str(tmp_path), sequence_length=4)
+    b = ds.collate_fn([d[i] for i in range(3)])
+    assert np.array_equal(b["rgb_emb"].numpy(), g["ds/collate/rgb"])
+    assert np.array_equal(b["flow_frames"].numpy(), g["ds/collate/flow"])
+    assert np.array_equal(b["labels"].numpy(), g["ds/collate/labels"])
+
+
+def test_oracle_residual_mlp_matches_the_reference_class(golden):
+    g = golden["student"]
+    for c in mgs.MLP_CASES:
+        x, w1, b1, w2, b2 = mgs.mlp_inputs(c)
+        sd = {"residual_mlp.fc1.weight": w1, "residual_mlp.fc1.bias": b1, "residual_mlp.fc2.weight": w2, "residual_mlp.fc2.bias": b2}
+        y = ostudent.residual_mlp(sd, x, c["alpha"])
+        assert np.abs(y.numpy() - g[f"mlp/{c['name']}/y"]).max() < 1e-6

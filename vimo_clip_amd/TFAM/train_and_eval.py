@@ -11,6 +11,8 @@ import argparse
 import json
 import time
 
+import os
+
 import numpy as np
 import torch
 
@@ -123,6 +125,13 @@ class GraphedEvalForward:
         if key not in self._graphs and len(self._graphs) >= self.max_graphs:
             return self.model(rgb, mot, mask_rgb=mr, mask_flow=mf)              # too many shapes: eager
         rgb, mot, mr, mf = self._pad(rgb, Tr), self._pad(mot, Tf), self._pad(mr, Tr), self._pad(mf, Tf)
+        # a captured per-op forward bakes the pointers of 16-bit weight copies that an optimiser step invalidates ->
+        # graphs die with the weight epoch they were captured in.  (The fused chain reads persistent packs rewritten in place,
+        # refreshed here before the replay; its graphs survive, but are dropped with the others for simplicity.)
+        from .. import autograd_ops as ag
+        if getattr(self, "_epoch", None) != ag.weights.epoch:
+            self._graphs.clear()
+            self._epoch = ag.weights.epoch
         g = self._graphs.get(key)
         if g is None:
             def fwd(a, b, c, d):
@@ -182,10 +191,23 @@ class ModelTrainer:
         return float(stats[0] / stats[1].clamp(min=1)), float(self.mAP_metric.compute(distributed=self.world > 1))
 
     def save_checkpoint(self, val_loss, val_mAP, epoch, best=False, path=None):
-        state = {"epoch": epoch, "state_dict": self.model.state_dict(), "optimizer": self.optimizer.state_dict(),
+        """:133-148: the checkpoint dict is written as ``<checkpoint_dir>/best_model.pth`` only when the validation mAP improves
+        (rank 0; ``checkpoint_dir = None`` keeps it in memory only).  Tensors are cloned: ``state_dict()`` returns views into
+        the gradient arena, and optimiser moments are live buffers."""
+        from ..checkpoint import snapshot
+        improved = val_mAP > self.best_val_mAP
+        if improved:
+            self.best_val_mAP, self.best_val_loss = val_mAP, val_loss
+        opt = {k: (v.detach().to("cpu", copy=True) if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()}
+        state = {"epoch": epoch, "state_dict": snapshot(self.model), "optimizer": opt,
                  "scheduler": self.scheduler.state_dict(), "best_val_loss": self.best_val_loss, "best_val_mAP": self.best_val_mAP}
-        if path and self.rank == 0:
-            torch.save(state, path)
+        ckpt_dir = getattr(self.config, "checkpoint_dir", None)
+        if self.rank == 0:
+            if improved and ckpt_dir:
+                os.makedirs(ckpt_dir, exist_ok=True)
+                torch.save(state, os.path.join(ckpt_dir, "best_model.pth"))
+            if path:
+                torch.save(state, path)
         return state
 
     def train(self):
@@ -193,8 +215,7 @@ class ModelTrainer:
         for epoch in range(self.config.epochs):
             tl, tm = self.train_epoch(epoch)
             vl, vm = self.validate(epoch)
-            if vm > self.best_val_mAP:
-                self.best_val_mAP, self.best_val_loss = vm, vl
+            self.save_checkpoint(vl, vm, epoch)          # best_model.pth when the mAP improved (:157-160)
             self.scheduler.step()
             if self.rank == 0:
                 print(json.dumps({"epoch": epoch + 1, "train_loss": tl, "train_mAP": tm, "val_loss": vl, "val_mAP": vm,
@@ -207,6 +228,13 @@ class ModelTester:
         self.model, self.test_set, self.config, self.rank, self.world = model, test_set, config, rank, world
         _, self.mAP_metric = task_objects(config)
         self._graphed_eval = GraphedEvalForward(model, config) if getattr(config, "use_graphs", False) else None
+
+    def load_best_model(self, checkpoint_dir):
+        """:186-191 — weights-only load of ``best_model.pth`` (keys with or without the DataParallel ``module.`` prefix)."""
+        from ..checkpoint import load_state_dict
+        load_state_dict(self.model, os.path.join(checkpoint_dir, "best_model.pth"))
+        self.model.eval()
+        return self
 
     def evaluate(self, k=5):
         """sigmoid top-k predictions + micro mAP (:193-248)."""
@@ -272,7 +300,16 @@ def run(cfg, rank=0, world=1, limit=2048, train_annotations=None, val_annotation
     if cfg.mode in ("train", "both"):
         out["best_val_metric"] = ModelTrainer(model, train_set, val_set, cfg, rank, world).train()
     if cfg.mode in ("test", "both"):
-        out["test_metric"], _ = ModelTester(model, val_set, cfg, rank, world).evaluate()
+        tester = ModelTester(model, val_set, cfg, rank, world)
+        best = os.path.join(cfg.checkpoint_dir, "best_model.pth") if getattr(cfg, "checkpoint_dir", None) else None
+        if best and os.path.exists(best):              # :404-406: the tester evaluates the best checkpoint, not the last epoch
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()                          # rank 0 has finished writing it
+            tester.load_best_model(cfg.checkpoint_dir)
+        elif cfg.mode == "test":
+            raise FileNotFoundError(f"mode='test' needs {best or '<checkpoint_dir>/best_model.pth'} (TFAM/train_and_eval.py:404-406)")
+        out["test_metric"], _ = tester.evaluate()
     return out
 
 

@@ -25,6 +25,8 @@ SIGNATURES = {
     "vmc_error_string": (c_char_p, [I]),
     "vmc_preprocess_patches_u8": (I, [P, P, I, I, I, I, I, I, P]),
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
+    "vmc_patches_u8_exact": (I, [P, P, I, I, I, I, I, I, P]),
+    "vmc_patches_f32_split": (I, [P, P, I, I, I, I, I, P]),
     "vmc_resample_u8": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "vmc_linear": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),
     "vmc_linear_preact": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, I, I, I, P]),

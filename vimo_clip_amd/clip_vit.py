@@ -93,6 +93,7 @@ class VisionTransformer(nn.Module):
         self.residual_dtype = residual_dtype
         self._w16 = {}          # name -> (param version, 16-bit copy)
         self.fuse_add_ln = True  # False: x += GEMM in the epilogue (fp32 read-modify-write), plain LayerNorm after it
+        self.exact_patch_embed = True   # split-precision patch GEMM (fp32-accurate; +0.2 % FLOPs): see patch_operands()
         self.frame_chunk = 256  # frames per pass (bounds activation memory; F*N*4D*2 B for the MLP buffer)
         self._init_weights()
 
@@ -116,13 +117,52 @@ class VisionTransformer(nn.Module):
         from .autograd_ops import weights          # one cache for the inference and training paths
         return weights.get(param, self.compute_dtype, transposed=transposed, pad_k=pad_k)
 
+    def patch_operands(self, mode: str):
+        """Weight / bias / alpha of the inference patch-embedding GEMM for a patch layout (ops.patches_u8_exact,
+        ops.patches_f32_split or the plain single-slice layout).  The split layouts carry the weight as hi + lo 16-bit halves,
+        so the GEMM is fp32-accurate (include/vmc.h, vmc_patches_u8_exact).  One-off weight preparation, cached per weight
+        version like every other 16-bit compute copy."""
+        from .autograd_ops import weights
+        from .oracle_free_constants import CLIP_MEAN, CLIP_STD
+        w = self.conv1.weight
+        key = (mode, self.compute_dtype, weights.epoch, w._version, w.data_ptr())
+        hit = getattr(self, "_patch_ops", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        dt16, p = self.compute_dtype, self.patch_size
+        D, k = w.shape[0], 3 * p * p
+        kpad = (k + 63) // 64 * 64
+        w2 = w.detach().float().reshape(D, 3, p * p)
+
+        def split(wm):          # [D, k] fp32 -> 16-bit hi, lo (zero padded to kpad)
+            hi = wm.to(dt16)
+            lo = (wm - hi.float()).to(dt16)
+            pad = lambda t: torch.nn.functional.pad(t, (0, kpad - k))
+            return pad(hi), pad(lo)
+
+        if mode == "u8_exact":
+            istd = torch.tensor([1.0 / s_ for s_ in CLIP_STD], device=w.device).view(1, 3, 1)
+            mean = torch.tensor(CLIP_MEAN, device=w.device).view(1, 3, 1)
+            hi, lo = split((w2 * istd).reshape(D, k))
+            bias = (-255.0 * (w2.double() * (mean.double() * istd.double())).sum(dim=(1, 2))).float().contiguous()
+            ops_ = (torch.cat([hi, lo], dim=1).contiguous(), bias, 1.0 / 255.0)
+        elif mode == "f32_split":
+            hi, lo = split(w2.reshape(D, k))
+            ops_ = (torch.cat([hi, hi, lo], dim=1).contiguous(), None, 1.0)
+        else:
+            ops_ = (self.w16("conv1", w, pad_k=True), None, 1.0)
+        self._patch_ops = (key, ops_)
+        return ops_
+
     def invalidate_weight_cache(self):
         from .autograd_ops import weights
         weights.clear()
 
     # ---- inference forward ---------------------------------------------------------------------------
     @torch.no_grad()
-    def _encode_patches(self, patches: torch.Tensor, F: int) -> torch.Tensor:
+    def _encode_patches(self, patches: torch.Tensor, F: int, trace: list = None, patch_mode: str = "plain") -> torch.Tensor:
+        """trace (tests only): receives (stage, copy of the residual stream [F*N, D]) after ln_pre and after each residual add
+        of every block but the last MLP add (there only the class rows are formed)."""
         dt16, D, H = self.compute_dtype, self.width, self.heads
         g = self.input_resolution // self.patch_size
         g2, N = g * g, g * g + 1
@@ -130,8 +170,8 @@ class VisionTransformer(nn.Module):
         x = torch.empty((F * N, D), dtype=self.residual_dtype, device=dev)
         pos = self.positional_embedding.detach()
         # K1: patch GEMM, epilogue adds positional_embedding[1 + patch] and scatters into token rows
-        ops.linear(patches, self.w16("conv1", self.conv1.weight, pad_k=True), res=pos[1:], out=x,
-                   out_row_group=g2, res_row_mod=g2)
+        w_patch, b_patch, alpha = self.patch_operands(patch_mode)
+        ops.linear(patches, w_patch, bias=b_patch, alpha=alpha, res=pos[1:], out=x, out_row_group=g2, res_row_mod=g2)
         ops.set_class_rows(x, self.class_embedding.detach(), pos[0], F, D, N * D, dt16)
         xf32 = self.residual_dtype == torch.float32
         # ln_pre in place on the residual stream
@@ -139,6 +179,8 @@ class VisionTransformer(nn.Module):
             ops.layernorm(x, self.ln_pre.weight, self.ln_pre.bias, dt16, out16=False, out32=True, y32=x)
         else:
             self._ln_inplace16(x, self.ln_pre)
+        if trace is not None:
+            trace.append(("ln_pre", x.float().clone()))
         fused = xf32 and D % 256 == 0 and self.fuse_add_ln   # residual add fused into the next LayerNorm (vmc_add_layernorm_fwd)
         blocks = list(self.transformer.resblocks)
         h = None
@@ -155,6 +197,8 @@ class VisionTransformer(nn.Module):
             else:
                 ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x, out=x)
                 h, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16)
+            if trace is not None:
+                trace.append((f"blk{i}.attn", x.float().clone()))
             u = ops.linear(h, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
             last = i + 1 == len(blocks)
             if fused:
@@ -170,6 +214,8 @@ class VisionTransformer(nn.Module):
                 h = None
                 if last:
                     cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
+            if trace is not None and not (fused and last):
+                trace.append((f"blk{i}.mlp", x.float().clone()))
             del u, o
         return ops.linear(cls, self.w16("proj", self.proj, transposed=True), out_dtype=torch.float32)
 
@@ -192,8 +238,12 @@ class VisionTransformer(nn.Module):
         outs = []
         for s in range(0, frames_u8.shape[0], self.frame_chunk):
             fr, wrap = self.fit_frames_u8(frames_u8[s:s + self.frame_chunk], wrap_quirk, crop_mode)
-            patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap)
-            outs.append(self._encode_patches(patches, fr.shape[0]))
+            if self.exact_patch_embed:
+                patches = ops.patches_u8_exact(fr, self.patch_size, self.compute_dtype, wrap)
+                outs.append(self._encode_patches(patches, fr.shape[0], patch_mode="u8_exact"))
+            else:
+                patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap)
+                outs.append(self._encode_patches(patches, fr.shape[0]))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     @torch.no_grad()
@@ -202,7 +252,11 @@ class VisionTransformer(nn.Module):
         outs = []
         for s in range(0, pixel_values.shape[0], self.frame_chunk):
             pv = pixel_values[s:s + self.frame_chunk]
-            outs.append(self._encode_patches(ops.patches_f32(pv, self.patch_size, self.compute_dtype), pv.shape[0]))
+            if self.exact_patch_embed:
+                outs.append(self._encode_patches(ops.patches_f32_split(pv, self.patch_size, self.compute_dtype), pv.shape[0],
+                                                 patch_mode="f32_split"))
+            else:
+                outs.append(self._encode_patches(ops.patches_f32(pv, self.patch_size, self.compute_dtype), pv.shape[0]))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

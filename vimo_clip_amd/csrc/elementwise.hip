@@ -128,6 +128,128 @@ extern "C" int vmc_patches_f32(const float* pixel_values, void* patches, int F, 
   return 0;
 }
 
+// ---- split-precision patch operands (inference): the patch-embedding GEMM is 0.2 % of the encoder's FLOPs but its 16-bit
+// operand rounding was the largest single contribution to the embedding error (tests/test_gpu_encoder.py per-stage trace: the
+// stream error right after ln_pre was 60-75 % of the final one).  Two extra K slices make that GEMM fp32-accurate:
+//   u8 frames:   A = [v | v]            (v = raw pixel 0..255, exact in 16 bits),  W = [W'_hi | W'_lo],  W' = W / std_c,
+//                bias' = -255 sum_k W mean_c / std_c,  alpha = 1/255   ->  alpha (A W^T + bias') = sum_k ((v/255 - mean)/std) W
+//   f32 pixels:  A = [x_hi | x_lo | x_hi],  W = [W_hi | W_hi | W_lo]   (x_lo = x - x_hi: the product's cross terms)
+template <typename T>
+__global__ void __launch_bounds__(256) patches_u8_exact_kernel(const uint8_t* __restrict__ frames, uint16_t* __restrict__ patches,
+                                                               int F, int R, int p, int kpad, int wrap) {
+  const int g = R / p;
+  const int quads_per_row = R >> 2;
+  const size_t total = (size_t)F * 3 * R * quads_per_row;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xq = (int)(i % quads_per_row);
+    size_t t = i / quads_per_row;
+    const int y = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % 3);
+    const int f = (int)(t / 3);
+    const uint32_t px = *(const uint32_t*)(frames + i * 4);
+    const int py = y / p, dy = y % p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = xq * 4 + j;
+      uint32_t v = (px >> (8 * j)) & 0xFFu;
+      if (wrap) v = (256u - v) & 0xFFu;
+      const int pxi = x / p, dx = x % p;
+      const size_t prow = ((size_t)f * g + py) * g + pxi;
+      const uint16_t h = T::from_f32((float)v);              // integers <= 255 are exact in bf16 and f16
+      uint16_t* dst = patches + prow * (2 * (size_t)kpad) + (c * p + dy) * p + dx;
+      dst[0] = h;
+      dst[kpad] = h;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) patches_f32_split_kernel(const float* __restrict__ pix, uint16_t* __restrict__ patches, int F, int R,
+                                                                int p, int kpad) {
+  const int g = R / p;
+  const int quads_per_row = R >> 2;
+  const size_t total = (size_t)F * 3 * R * quads_per_row;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xq = (int)(i % quads_per_row);
+    size_t t = i / quads_per_row;
+    const int y = (int)(t % R);
+    t /= R;
+    const int c = (int)(t % 3);
+    const int f = (int)(t / 3);
+    const float4 px = *(const float4*)(pix + i * 4);
+    const float v[4] = {px.x, px.y, px.z, px.w};
+    const int py = y / p, dy = y % p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = xq * 4 + j;
+      const int pxi = x / p, dx = x % p;
+      const size_t prow = ((size_t)f * g + py) * g + pxi;
+      const uint16_t hi = T::from_f32(v[j]);
+      const uint16_t lo = T::from_f32(v[j] - T::to_f32(hi));
+      uint16_t* dst = patches + prow * (3 * (size_t)kpad) + (c * p + dy) * p + dx;
+      dst[0] = hi;
+      dst[kpad] = lo;
+      dst[2 * kpad] = hi;
+    }
+  }
+}
+
+__global__ void zero_pad_cols_multi_kernel(uint16_t* __restrict__ patches, size_t rows, int k, int kpad, int parts) {
+  const int padw = kpad - k;
+  const size_t total = rows * padw * parts;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / ((size_t)padw * parts);
+    const int rem = (int)(i % ((size_t)padw * parts));
+    patches[row * ((size_t)kpad * parts) + (size_t)(rem / padw) * kpad + k + (rem % padw)] = 0;
+  }
+}
+
+extern "C" int vmc_patches_u8_exact(const uint8_t* frames, void* patches, int F, int R, int p, int kpad, int wrap_quirk, int dtype16,
+                                    void* stream) {
+  if (!frames || !patches || F <= 0 || R <= 0 || p <= 0) return VMC_E_ARG;
+  if (R % p || R % 4 || kpad < 3 * p * p || kpad % 8) return VMC_E_SHAPE;
+  if ((uintptr_t)frames & 3) return VMC_E_ALIGN;
+  const size_t total = (size_t)F * 3 * R * (R / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const int k = 3 * p * p;
+  if (kpad > k) {
+    const size_t rows = (size_t)F * (R / p) * (R / p);
+    hipLaunchKernelGGL(zero_pad_cols_multi_kernel, dim3(grid_for(rows * (kpad - k) * 2, 256)), dim3(256), 0, s, (uint16_t*)patches, rows, k, kpad, 2);
+    VMC_CHECK_LAUNCH();
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(patches_u8_exact_kernel<BF16>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, (uint16_t*)patches, F, R, p, kpad, wrap_quirk);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(patches_u8_exact_kernel<F16>, dim3(grid_for(total, 256)), dim3(256), 0, s, frames, (uint16_t*)patches, F, R, p, kpad, wrap_quirk);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vmc_patches_f32_split(const float* pixel_values, void* patches, int F, int R, int p, int kpad, int dtype16, void* stream) {
+  if (!pixel_values || !patches || F <= 0 || R <= 0 || p <= 0) return VMC_E_ARG;
+  if (R % p || R % 4 || kpad < 3 * p * p || kpad % 8) return VMC_E_SHAPE;
+  if ((uintptr_t)pixel_values & 15) return VMC_E_ALIGN;
+  const size_t total = (size_t)F * 3 * R * (R / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const int k = 3 * p * p;
+  if (kpad > k) {
+    const size_t rows = (size_t)F * (R / p) * (R / p);
+    hipLaunchKernelGGL(zero_pad_cols_multi_kernel, dim3(grid_for(rows * (kpad - k) * 3, 256)), dim3(256), 0, s, (uint16_t*)patches, rows, k, kpad, 3);
+    VMC_CHECK_LAUNCH();
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(patches_f32_split_kernel<BF16>, dim3(grid_for(total, 256)), dim3(256), 0, s, pixel_values, (uint16_t*)patches, F, R, p, kpad);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(patches_f32_split_kernel<F16>, dim3(grid_for(total, 256)), dim3(256), 0, s, pixel_values, (uint16_t*)patches, F, R, p, kpad);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- Pillow-exact antialiased resample of planar u8 images along one axis (K0) --------------
 // out[p, i, j] = clip8((2^21 + sum_x in[...] * coeff[o, x]) >> 22), the fixed-point arithmetic of Pillow's
 // ImagingResample{Horizontal,Vertical}_8bpc; bounds/coeffs come from the host (float64, Pillow's precompute_coeffs).

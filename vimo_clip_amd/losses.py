@@ -21,10 +21,10 @@ class _DistillFn(torch.autograd.Function):
         rows = student.numel() // E
         s = student.contiguous().float()
         # teacher may be the strided slice rgb_emb[:, :-1] of train.py:98: rows_per_clip rows out of a longer clip
-        if teacher.dim() == 3 and teacher.stride(-1) == 1 and teacher.stride(1) == E:
-            rows_per_clip, clip_stride = teacher.shape[1], teacher.stride(0)
-            t = teacher if teacher.dtype == torch.float32 else teacher.float()
-        else:
+        if teacher.dtype == torch.float32 and teacher.dim() == 3 and teacher.stride(-1) == 1 and teacher.stride(1) == E:
+            t = teacher                                 # strided view read in place: strides of the tensor the kernel gets
+            rows_per_clip, clip_stride = t.shape[1], t.stride(0)
+        else:                                           # other dtypes (f16 / f64 stores): a dense fp32 copy, dense strides
             t = teacher.contiguous().float()
             rows_per_clip, clip_stride = rows, rows * E
         loss = torch.empty((), dtype=torch.float32, device=s.device)

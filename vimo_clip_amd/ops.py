@@ -191,6 +191,32 @@ def patches_f32(pixel_values: torch.Tensor, patch: int, dtype16) -> torch.Tensor
     return out
 
 
+def patches_u8_exact(frames_u8: torch.Tensor, patch: int, dtype16, wrap_quirk: bool) -> torch.Tensor:
+    """[F*g*g, 2*kpad] = [v | v]: raw pixels as exact 16-bit integers (vmc_patches_u8_exact)."""
+    F, C, R, R2 = frames_u8.shape
+    if C != 3 or R != R2 or frames_u8.dtype != torch.uint8:
+        raise ValueError("frames must be u8 [F,3,R,R]")
+    frames_u8 = frames_u8.contiguous()
+    g = R // patch
+    kpad = _kpad(3 * patch * patch)
+    out = torch.empty((F * g * g, 2 * kpad), dtype=dtype16, device=frames_u8.device)
+    check(lib.vmc_patches_u8_exact(ptr(frames_u8), ptr(out), F, R, patch, kpad, int(wrap_quirk), dt(dtype16), stream()), "patches_u8_exact")
+    return out
+
+
+def patches_f32_split(pixel_values: torch.Tensor, patch: int, dtype16) -> torch.Tensor:
+    """[F*g*g, 3*kpad] = [x_hi | x_lo | x_hi] (vmc_patches_f32_split)."""
+    F, C, R, R2 = pixel_values.shape
+    if C != 3 or R != R2:
+        raise ValueError("pixel_values must be [F,3,R,R]")
+    pixel_values = pixel_values.float().contiguous()
+    g = R // patch
+    kpad = _kpad(3 * patch * patch)
+    out = torch.empty((F * g * g, 3 * kpad), dtype=dtype16, device=pixel_values.device)
+    check(lib.vmc_patches_f32_split(ptr(pixel_values), ptr(out), F, R, patch, kpad, dt(dtype16), stream()), "patches_f32_split")
+    return out
+
+
 def set_class_rows(x: torch.Tensor, a, b, F: int, D: int, row_stride: int, dtype16):
     check(lib.vmc_set_class_rows(ptr(x), ptr(a), ptr(b), F, D, row_stride, dt(x), dt(dtype16), stream()), "set_class_rows")
 

@@ -70,6 +70,7 @@ def train(args):
     optimizer = FusedAdam(arena, lr=args.learning_rate)
     reducer = parallel.GradientAllReducer(arena.flat_grad).attach(arena)     # buckets go out during the backward
     best = float("inf")
+    ckpt_dir = getattr(args, "checkpoint_dir", None)       # reference: checkpoints/<run timestamp> (train.py:69-74)
     for epoch in range(args.epochs):
         model.train()
         t0, nframes = time.time(), 0
@@ -83,6 +84,11 @@ def train(args):
             nframes += frames.shape[0] * frames.shape[1]
         torch.cuda.synchronize()
         vd, vc, vt = evaluate(model, val_set, device, args.distillation_loss_mode, args.class_positive_weight, args.batch_size, rank, world, single)
+        if rank == 0 and ckpt_dir:                          # train.py:164-172: every epoch + the best-so-far copy
+            from .checkpoint import save_state_dict
+            save_state_dict(model, f"{ckpt_dir}/student_epoch_{epoch + 1}.pth")
+            if vt < best:
+                save_state_dict(model, f"{ckpt_dir} - best/student_best.pth")
         best = min(best, vt)
         if rank == 0:
             print(json.dumps({"epoch": epoch + 1, "val_distill": vd, "val_class": vc, "val_total": vt,
@@ -103,6 +109,8 @@ if __name__ == "__main__":
     p.add_argument("--class_positive_weight", type=int, default=9)
     p.add_argument("--residual_alpha", type=float, default=0.1)
     p.add_argument("--grad_clip_norm", type=float, default=None)
+    p.add_argument("--checkpoint_dir", default=None, help="write student_epoch_N.pth here and student_best.pth into '<dir> - best' "
+                                                           "(the reference uses checkpoints/<timestamp>); omitted = no files")
     p.add_argument("--single_label", action="store_true", help="MammalNet variant: CrossEntropy on labels.argmax(1)")
     p.add_argument("--clip_embeddings_dir", default=None, help="HDF5 file of teacher embeddings (reference layout)")
     p.add_argument("--flow_videos_dir", default=None)
