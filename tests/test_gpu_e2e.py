@@ -32,7 +32,7 @@ def test_tfam_training_trajectory_and_map_parity():
     tr = SyntheticEmbeddingDataset(ytr, D, tmin=9, tmax=20, seed=5, signal=0.6)
     va = SyntheticEmbeddingDataset(yva, D, tmin=9, tmax=20, seed=6, signal=0.6)
     sd0 = synth.tfam_state_dict(D, H, L, FF, C, 77)
-    cfg = Config(epochs=1, batch_size=BS, d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, dropout=0.0, mlp_dropout=0.0, device="cuda")
+    cfg = Config(epochs=1, batch_size=BS, d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, dropout=0.0, mlp_dropout=0.0, device="cuda", checkpoint_dir=None)
     model = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda()
     model.load_state_dict(sd0, strict=True)
     trainer = ModelTrainer(model, tr, va, cfg)

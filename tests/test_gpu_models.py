@@ -269,7 +269,7 @@ def test_tfam_single_label_training_learns():
     # class-dependent synthetic embeddings (accuracy far above chance) and the YAML/run() plumbing must hold together
     from vimo_clip_amd.TFAM.train_and_eval import Config, run
     cfg = Config(task="singlelabel", motion_key="frame_diff", num_classes=10, d_model=128, nhead=4, num_layers=1, dim_feedforward=256,
-                 epochs=3, batch_size=16, dropout=0.0, mlp_dropout=0.0, device="cuda:0", mode="both")
+                 epochs=3, batch_size=16, dropout=0.0, mlp_dropout=0.0, device="cuda:0", mode="both", checkpoint_dir=None)
     res = run(cfg, limit=512)
     assert res["task"] == "singlelabel" and res["best_val_metric"] > 0.5 and res["test_metric"] > 0.5, res
 
@@ -364,7 +364,7 @@ def test_residual_mlp_vs_reference_class(golden, c):
     ref = torch.from_numpy(g[f"mlp/{c['name']}/y"])
     for dtype, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
         m = ResidualMLP(c["E"], alpha=c["alpha"], compute_dtype=dtype).cuda()
-        assert float(m.fc2.weight.abs().max()) == 0.0 and float(m.fc2.bias.abs().max()) == 0.0
+        assert float(m.fc2.weight.detach().abs().max()) == 0.0 and float(m.fc2.bias.detach().abs().max()) == 0.0
         with torch.no_grad():
             y0 = m(x.cuda())
             assert torch.equal(y0.cpu().float(), x) or (y0.cpu().float() - x).abs().max() <= tol * x.abs().max()
@@ -383,3 +383,51 @@ def test_residual_mlp_vs_reference_class(golden, c):
             relw = ((m.fc1.weight.grad.cpu()[:8] - dw_ref).norm() / dw_ref.norm()).item()
             print(f"   backward: dx rel L2 {rel:.3e}, dfc1.weight rel L2 {relw:.3e}")
             assert rel <= 2e-2 and relw <= 3e-2
+
+
+def test_distillation_loss_strided_teacher_in_other_dtypes():
+    """teacher = rgb_emb[:, :-1] stored as f16 / f64 -- strides must be taken from the tensor the kernel gets."""
+    from vimo_clip_amd.losses import distillation_loss
+    B, T, E = 3, 5, 64
+    s = synth.normal(5, "s", (B, T, E)).cuda().requires_grad_(True)
+    t_full = synth.normal(5, "t", (B, T + 1, E))
+    ref = ostudent.distillation_loss(s.detach().cpu(), t_full[:, :-1], "cosine")
+    for dt_ in (torch.float32, torch.float64, torch.float16):
+        tt = t_full.to(dt_).cuda()
+        loss = distillation_loss(s, tt[:, :-1, :], mode="cosine")
+        tol = 2e-3 if dt_ == torch.float16 else 1e-5
+        assert abs(loss.item() - float(ref)) <= tol * abs(float(ref)), (dt_, loss.item(), float(ref))
+
+
+def test_fused_adam_grad_clip_matches_torch():
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    ps = [torch.nn.Parameter(synth.normal(8, f"p{i}", sh).cuda()) for i, sh in enumerate([(64, 32), (32,), (8, 8)])]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    arena = GradArena(ps)
+    opt = FusedAdam(arena, lr=1e-2)
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            g = synth.normal(9 + step, f"g{i}", tuple(p.shape)).cuda() * 3.0
+            p._vmc_grad.copy_(g)
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.7)
+        topt.step()
+        opt.step(max_grad_norm=0.7)
+    for p, r in zip(ps, ref):
+        assert (p.detach() - r.detach()).abs().max().item() <= 2e-6 * max(1.0, r.abs().max().item())
+
+
+def test_tfam_best_checkpoint_round_trip(tmp_path):
+    """train() writes best_model.pth (reference dict layout, module.-prefixed keys), the tester reloads it."""
+    from vimo_clip_amd.TFAM import train_and_eval as te
+    cfg = te.Config(epochs=2, batch_size=8, d_model=512, num_layers=1, dropout=0.0, mlp_dropout=0.0, checkpoint_dir=str(tmp_path), mode="both")
+    res = te.run(cfg, limit=64)
+    ck = torch.load(str(tmp_path / "best_model.pth"), weights_only=True)
+    assert set(ck) == {"epoch", "state_dict", "optimizer", "scheduler", "best_val_loss", "best_val_mAP"}
+    assert all(k.startswith("module.") for k in ck["state_dict"])
+    assert abs(ck["best_val_mAP"] - res["best_val_metric"]) < 1e-9
+    m2 = te.build_model(cfg)
+    te.ModelTester(m2, None, cfg).load_best_model(str(tmp_path))
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), ck["state_dict"]["module." + k]), k

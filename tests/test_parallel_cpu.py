@@ -102,3 +102,22 @@ def test_shard_range():
     from vimo_clip_amd.parallel import shard_range
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 8)]
     assert [shard_range(10, r, 4, drop_last=False) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+
+
+def test_grad_clip_uses_the_norm_of_the_averaged_gradient():
+    """clipping after a SUM all-reduce must see ||sum|| / world, or N GPUs clip N times too hard."""
+    import math
+
+    from vimo_clip_amd.optim import clipped_grad_scale
+    g = torch.tensor([3.0, 4.0])                       # per-rank gradient, identical on both ranks: average norm 5
+    for world in (1, 2, 8):
+        s = clipped_grad_scale(float((g * world).norm()), 1.0 / world, max_grad_norm=1.0)
+        eff = g * world * s                             # what the optimiser applies
+        ref = g.clone()
+        torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(ref)], 1.0)      # torch on the averaged gradient
+        p = torch.nn.Parameter(torch.zeros(2))
+        p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p], 1.0)
+        assert torch.allclose(eff, p.grad, rtol=1e-6), (world, eff, p.grad)
+        assert math.isclose(float(eff.norm()), 1.0, rel_tol=1e-5)
+    assert clipped_grad_scale(0.5, 0.25, max_grad_norm=10.0) == 0.25   # below the threshold: only the averaging factor

@@ -58,6 +58,15 @@ class GradArena:
         return [self.flat_grad[s:min(self.numel, s + n)] for s in range(0, self.numel, n)]
 
 
+def clipped_grad_scale(sum_grad_norm: float, grad_scale: float, max_grad_norm: float) -> float:
+    """Scale to apply to the (rank-summed) arena gradient so that it equals ``clip_grad_norm_`` applied to the AVERAGED
+    gradient (train.py:105-106 runs on one process; under data parallelism the arena holds the SUM until ``grad_scale`` =
+    1/world is applied inside the Adam kernel): norm of the average = ||sum|| * grad_scale, torch's coefficient
+    min(1, max_norm / (norm + 1e-6)), final factor = grad_scale * coefficient."""
+    total = sum_grad_norm * abs(grad_scale)
+    return grad_scale * min(1.0, max_grad_norm / (total + 1e-6))
+
+
 class FusedAdam:
     """Adam / AdamW over a GradArena: one kernel launch per step."""
 
@@ -75,10 +84,7 @@ class FusedAdam:
     def step(self, grad_scale: float = 1.0, max_grad_norm=None):
         a = self.arena
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
-            # the norm torch.nn.utils.clip_grad_norm_ sees is that of the AVERAGED gradient: the arena holds the SUM over
-            # ranks until grad_scale (1/world) is applied inside the Adam kernel
-            total = float(a.grad_norm().item()) * abs(grad_scale)
-            grad_scale = grad_scale * min(1.0, max_grad_norm / (total + 1e-6))
+            grad_scale = clipped_grad_scale(float(a.grad_norm().item()), grad_scale, max_grad_norm)
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         check(lib.vmc_adam_step(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, float(lr),
