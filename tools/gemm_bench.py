@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--shapes", nargs="*", default=DEFAULT)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--variants", type=int, nargs="*", default=[1], help="0 two-stage, 1 8-phase, 2 persistent")
+    ap.add_argument("--variants", type=lambda x: int(x, 0), nargs="*", default=[1],
+                    help="vmc_linear_variant values: 0 two-stage, 1 default, 2 no tail split; | 0x10 LDS-staged epilogue, | 0x20 nt stores")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--act", type=int, default=0, help="0 none, 1 QuickGELU (adds a bias too)")
     ap.add_argument("--res32", action="store_true", help="fp32 residual in + fp32 out in place (out_proj / c_proj epilogue)")
@@ -32,11 +33,10 @@ def main():
         out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if args.res32 else dt)
         bias = torch.randn(N, device="cuda") if (args.act or args.res32) else None
         kw = dict(bias=bias, out=out, act=args.act, res=out if args.res32 else None)
-        from vimo_clip_amd._lib import lib
         res = {}
         for rnd in range(args.rounds):            # interleaved rounds in ONE process (variants share clocks/thermals)
             for var in args.variants:
-                lib.vmc_set_gemm_variant(var)
+                kw["variant"] = var
                 for _ in range(2):
                     ops.linear(a, w, **kw)
                 torch.cuda.synchronize()
@@ -50,7 +50,7 @@ def main():
         for var, ts in res.items():
             ts = sorted(ts)
             ms = ts[len(ts) // 2]
-            print(f"M={M} N={N} K={K} {args.dtype} variant {var}: median {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s"
+            print(f"M={M} N={N} K={K} {args.dtype} variant {var:#x}: median {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s"
                   f"  (min {ts[0]*1e3:.1f} us)", flush=True)
 
 

@@ -122,6 +122,11 @@ __device__ __forceinline__ void g8_iter(char* __restrict__ A0e, char* __restrict
   g8_mma<T>(acc[1][0], f.a, f.b0);
 }
 
+typedef unsigned int g8_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void g8_nt_store(const uint4& o, uint16_t* dst) {
+  __builtin_nontemporal_store((g8_u32x4){o.x, o.y, o.z, o.w}, (g8_u32x4*)dst);
+}
+
 template <typename T, int ACT>
 __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,6 +228,9 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
     }
     uint16_t* cbase = (uint16_t*)g.C + (size_t)(m0 + 64 * wm + r) * g.ldc + n0 + 32 * wn + 8 * q;
     uint16_t* zbase = g.zout ? (uint16_t*)g.zout + (size_t)(m0 + 64 * wm + r) * g.ldz + n0 + 32 * wn + 8 * q : nullptr;
+    const bool via_lds = (g.variant & VMC_GEMM_FLAG_LDS_EPILOGUE) != 0 && zbase == nullptr;
+    const bool nt_store = (g.variant & VMC_GEMM_FLAG_NT_STORE) != 0;
+    if (via_lds) __syncthreads();        // every wave is past its last fragment read: the 128 KiB of LDS are free
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -239,9 +247,32 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
                 make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
-          *(uint4*)(cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh) =
-              make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+          const uint4 o = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+          if (via_lds) {
+            // C tile image [256 rows][32 chunks of 16 B], chunk XOR (row & 31): conflict-free for this write (16 rows x 4
+            // chunks per instruction) and for the row-contiguous read below
+            const int row = 128 * mh + 64 * wm + 16 * mt + r, chunk = 16 * nh + 4 * wn + q;
+            *(uint4*)(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = o;
+          } else if (nt_store) {
+            g8_nt_store(o, cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh);
+          } else {
+            *(uint4*)(cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh) = o;
+          }
         }
+    if (via_lds) {
+      // whole 512-B rows per half wave: every store instruction writes 8 full 128-B lines (the direct epilogue above writes
+      // 16 rows x 64 B per instruction: half lines, completed later by a neighbouring wave)
+      __syncthreads();
+      uint16_t* ctile = (uint16_t*)g.C + (size_t)m0 * g.ldc + n0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * wave + 2 * i + (lane >> 5), chunk = lane & 31;
+        const uint4 o = *(const uint4*)(smem + row * 512 + ((chunk ^ (row & 31)) << 4));
+        uint4* dst = (uint4*)(ctile + (size_t)row * g.ldc + 8 * chunk);
+        if (nt_store) g8_nt_store(o, (uint16_t*)dst);
+        else *dst = o;
+      }
+    }
     return;
   }
   // Interior tile accumulating into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of

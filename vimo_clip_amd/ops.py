@@ -69,7 +69,7 @@ def cast32(x: torch.Tensor) -> torch.Tensor:
 
 def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = ACT_NONE, alpha: float = 1.0,
            out_dtype=None, out=None, out_row_group: int = 0, res_row_mod: int = 0, out_rows=None,
-           lda=None, z_out=None) -> torch.Tensor:
+           lda=None, z_out=None, variant=None) -> torch.Tensor:
     """C = alpha * act(A @ W^T + bias) + res   (vmc_linear).  a: [M,K] 16-bit (row stride lda), w16: [N,K].
     z_out: optional 16-bit [M,N] tensor that receives A @ W^T + bias before the activation (vmc_linear_preact)."""
     M = a.shape[0]
@@ -87,6 +87,11 @@ def linear(a: torch.Tensor, w16: torch.Tensor, bias=None, res=None, act: int = A
         check(lib.vmc_linear_preact(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), ptr(z_out), M, N, K, lda, w16.stride(0), out.stride(0),
                                     res.stride(0) if res is not None else 0, z_out.stride(0), act, float(alpha), dt(out),
                                     dt(res) if res is not None else 0, out_row_group, res_row_mod, dt(a), stream()), "linear_preact")
+        return out
+    if variant is not None:         # A/B measurements: large-problem kernel / epilogue options chosen per call (vmc_linear_variant)
+        check(lib.vmc_linear_variant(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), M, N, K, lda, w16.stride(0), out.stride(0),
+                                     res.stride(0) if res is not None else 0, act, float(alpha), dt(out), dt(res) if res is not None else 0,
+                                     out_row_group, res_row_mod, dt(a), int(variant), stream()), "linear_variant")
         return out
     check(lib.vmc_linear(ptr(a), ptr(w16), ptr(bias), ptr(res), ptr(out), M, N, K, lda, w16.stride(0), out.stride(0),
                          res.stride(0) if res is not None else 0, act, float(alpha), dt(out), dt(res) if res is not None else 0,
