@@ -431,3 +431,65 @@ def test_tfam_best_checkpoint_round_trip(tmp_path):
     te.ModelTester(m2, None, cfg).load_best_model(str(tmp_path))
     for k, v in m2.state_dict().items():
         assert torch.equal(v.cpu(), ck["state_dict"]["module." + k]), k
+
+
+def test_student_full_size_step_properties_vit_b32():
+    """BASELINE.json configs[2] at full size (ViT-B/32, 32 clips x 16 flow frames 224^2 per GPU: the bench's student leg), through
+    size-independent properties since the CPU oracle needs minutes for 512 frames:
+      (a) the loss is finite and every parameter gets a finite gradient;
+      (b) batch-split invariance: loss and gradients of the 32-clip batch equal the mean of those of its two 16-clip halves
+          (the losses are means over rows: train.py:98-100) although the GEMMs then take different tile paths;
+      (c) a 3-clip sample of the same batch: embeddings, loss and gradients against torch autograd through the fp32 oracle."""
+    from vimo_clip_amd.losses import classification_loss, distillation_loss
+    name, B, T, seed = "ViT-B/32", 32, 16, 83
+    R, H, E = synth.VIT_GEOMETRY[name][0], synth.VIT_GEOMETRY[name][4], synth.VIT_GEOMETRY[name][5]
+    m, sd = _student(name, seed, torch.bfloat16)
+    m.train()
+    vids = synth.randint_u8(seed, "vids", (B, T, 3, R, R)).cuda()
+    teacher = synth.normal(seed, "teacher", (B, T + 1, E)).cuda()
+    labels = synth.multi_hot_labels(seed, "labels", B, 140).cuda()
+    watch = ["classification_head.2.weight", "residual_mlp.fc1.weight", "visual_encoder.proj", "visual_encoder.transformer.resblocks.5.attn.in_proj_weight",
+             "visual_encoder.transformer.resblocks.0.mlp.c_fc.bias", "visual_encoder.conv1.weight", "visual_encoder.ln_pre.weight"]
+
+    def step(sl):
+        for p in m.parameters():
+            p.grad = None
+        emb, emb_d, logits = m(vids[sl])
+        loss = distillation_loss(emb_d, teacher[sl][:, :-1, :], mode="cosine") + classification_loss(logits, labels[sl], positive_weight=9)
+        loss.backward()
+        params = dict(m.named_parameters())
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params.values())
+        return loss.item(), {k: params[k].grad.detach().float().clone() for k in watch}, emb.detach()
+
+    full_loss, full_g, full_emb = step(slice(0, B))
+    l1, g1, _ = step(slice(0, B // 2))
+    l2, g2, _ = step(slice(B // 2, B))
+    assert np.isfinite(full_loss)
+    assert abs(full_loss - 0.5 * (l1 + l2)) <= 2e-4 * abs(full_loss), (full_loss, l1, l2)
+    for k in watch:
+        avg = 0.5 * (g1[k] + g2[k])
+        rel = ((full_g[k] - avg).norm() / (avg.norm() + 1e-20)).item()
+        print(f"split invariance {k}: rel L2 {rel:.2e}")
+        assert rel <= 1e-5, (k, rel)          # same arithmetic per clip whatever the batch split: only fp32 summation order differs (measured <= 3.5e-7)
+    # (c) three clips of the batch against the oracle (forward embeddings of the FULL pass, then a 3-clip step)
+    pick = [0, 15, 31]
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oe, oe_d, ol = ostudent.student_forward(sdo, vids[pick].cpu(), H, alpha=0.1, wrap_quirk=True)
+    err = (full_emb[pick].cpu().float() - oe.detach()).abs().max().item()
+    print(f"full-batch embeddings of clips {pick} vs oracle: max abs err {err:.3e} (|ref|max {oe.abs().max().item():.2f})")
+    assert err <= 8e-3 * max(1.0, oe.abs().max().item())
+    idx = torch.tensor(pick).cuda()
+    for p in m.parameters():
+        p.grad = None
+    emb, emb_d, logits = m(vids[idx])
+    loss = distillation_loss(emb_d, teacher[idx][:, :-1, :], mode="cosine") + classification_loss(logits, labels[idx], positive_weight=9)
+    loss.backward()
+    oloss = ostudent.distillation_loss(oe_d, teacher[idx].cpu()[:, :-1, :], "cosine") + ostudent.classification_loss(ol, labels[idx].cpu(), 9)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) <= 1e-2 * abs(oloss.item()), (loss.item(), oloss.item())
+    params = dict(m.named_parameters())
+    for k in watch:
+        ref, got = sdo[k].grad, params[k].grad.cpu().float()
+        rel = ((got - ref).norm() / (ref.norm() + 1e-20)).item()
+        print(f"3-clip step grad {k}: rel L2 {rel:.2e}")
+        assert rel <= 2e-2, (k, rel)          # measured 3.5e-3 .. 6.8e-3 (bf16 activations end to end)

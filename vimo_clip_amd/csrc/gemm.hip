@@ -330,7 +330,7 @@ extern "C" int vmc_linear_variant(const void* A, const void* W, const float* bia
                                   int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                                   int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                                   int dtype16, int variant, void* stream) {
-  if (variant < 0 || (variant & 0xF) >= VMC_GEMM_VARIANTS || (variant & ~0x3F)) return VMC_E_ARG;
+  if (variant < 0 || (variant & 0xF) >= VMC_GEMM_VARIANTS || (variant & ~0xFF)) return VMC_E_ARG;
   return linear_impl(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
                      res_row_mod, dtype16, variant, stream);
 }

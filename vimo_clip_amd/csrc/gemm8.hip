@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   int tm, tn;
   {
-    constexpr int GC = 4;
+    // VMC_GEMM_FLAG_GC_*: column-group width of the tile walk (A/B of the per-XCD L2 footprint); default 4
+    const int GC = (g.variant & 0xC0) == 0x40 ? 2 : (g.variant & 0xC0) == 0x80 ? 8 : (g.variant & 0xC0) == 0xC0 ? 16 : 4;
     const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
     const int cg = tile / gsz;
     if (cg < nfull) {
