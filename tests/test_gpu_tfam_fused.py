@@ -84,14 +84,24 @@ def test_hoisted_kv_gemm_bit_exact_on_integers(B, Tk):
     md = motion.cuda()
     check(lib.vmc_tfam_kv_fwd(ptr(md), ptr(wpack), ptr(ppack), ptr(ws), n, B, T, Tk, D, H, ff, L, C, 2, stream()), "tfam_kv_fwd")
     torch.cuda.synchronize()
-    # workspace layout (tfam_fused.hip tf_ws): y, xa, xb f32 [M,D]; qkv [M,3D]; q [M,D]; h [M,ff]; kv [Mk, L*2D]
+    # workspace layout (tfam_fused.hip tf_ws): y, xa, xb f32 [M,D]; qkv [M,3D]; q [M,D]; h [M,ff]; kv [Mk, L*2D] (V columns);
+    # pool [B,D]; g [B,D/2]; then the fragment-major buffers q, self k, cross k x L (tf_frag_off)
     al = lambda x: (x + 255) // 256 * 256
-    M = B * T
+    M, dh, KK = B * T, D // H, D // H // 32
     o = 3 * al(M * D * 4) + al(M * 3 * D * 2) + al(M * D * 2) + al(M * ff * 2)
     kv = ws[o:o + B * Tk * L * 2 * D * 2].view(torch.float16).view(B * Tk, L * 2 * D).float().cpu()
+    fe = B * D * 32
+    o += al(B * Tk * L * 2 * D * 2) + al(B * D * 2) + al(B * (D // 2) * 2) + 2 * al(fe * 2)
     ref = motion.double() @ wkv.double().t() + bias.double()
     assert ref.abs().max() < 2048
-    assert torch.equal(kv.double(), ref)
+    # index map of the fragment-major layout: element (clip, head, t, d)
+    clip, head, t, d = torch.meshgrid(torch.arange(B), torch.arange(H), torch.arange(Tk), torch.arange(dh), indexing="ij")
+    off = ((((clip * H + head) * 2 + (t // 16)) * KK + (d // 32)) * 64 + ((d // 8) % 4) * 16 + (t % 16)) * 8 + (d % 8)
+    for l in range(L):
+        kx = ws[o + l * al(fe * 2):o + l * al(fe * 2) + fe * 2].view(torch.float16).float().cpu()
+        k_got = kx[off.reshape(-1)].view(B, H, Tk, dh).permute(0, 2, 1, 3).reshape(B * Tk, D)
+        assert torch.equal(k_got.double(), ref[:, l * 2 * D:l * 2 * D + D]), f"K of layer {l} (fragment-major)"
+        assert torch.equal(kv[:, l * 2 * D + D:(l + 1) * 2 * D].double(), ref[:, l * 2 * D + D:(l + 1) * 2 * D]), f"V of layer {l}"
 
 
 @pytest.mark.parametrize("B", [1, 2, 8, 9, 16, 40])

@@ -46,10 +46,12 @@ struct TfArgs {
   const float* ln_b;
   float eps;
   float* xout;              // PRO_LN, optional: LN(A) as fp32 [M, K] (residual operand of a later launch)
-  const uint16_t* q;        // PRO_ATTN: q [B*T, ldq], k / v [B*Tk, ldk / ldv] (head h at columns h*DH..)
+  const uint16_t* q;        // PRO_ATTN: q / k in FRAGMENT-MAJOR layout (tf_frag_off), v row-major [B*Tk, ldv] (head h at columns h*DH..)
   const uint16_t* k;
   const uint16_t* v;
-  int ldq, ldk, ldv;
+  int ldv;
+  uint16_t* frag[2];        // EPI_ACT16, optional: output columns [i*frag_D, (i+1)*frag_D) go to frag[i] in fragment-major layout
+  int frag_D, frag_T, frag_H, frag_DH;   // instead of `out` (the q / k operands of the fused attention prologue)
   const uint8_t* kmask;     // [B, Tk], 1 = attend; may be null
   int T, Tk, H, B, cpb;     // cpb: clips per row block
   float scale;
@@ -68,6 +70,16 @@ struct TfArgs {
 
 __device__ __forceinline__ int swz16(int chunk, int row) { return chunk ^ (row & 15); }
 
+// Fragment-major layout of a q / k matrix: the 16 B an MFMA lane needs (token r of a 16-token tile, head-dim chunk 4 kk + qq)
+// sit at lane (16 qq + r) x 16 B of a 1-KiB record per (clip, head, token tile, kk) -- one fully coalesced wave load per
+// fragment, where row-major [token][feature] rows give 16 rows x 64 B per instruction (measured: the fragment-shaped loads
+// of 2 (clip, head) pairs cost 3.7 us of a 9.9 us launch).  Element offset of (clip, head, token t, head-dim d):
+__host__ __device__ __forceinline__ size_t tf_frag_off(int clip, int head, int t, int d, int H, int DH) {
+  const int KK = DH >> 5;
+  return ((((size_t)(clip * H + head) * 2 + (t >> 4)) * KK + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (t & 15)) * 8 + (d & 7);
+}
+__host__ __device__ __forceinline__ size_t tf_frag_elems(int clips, int H, int DH) { return (size_t)clips * H * 2 * (DH >> 5) * 512; }
+
 // (n tile, row block) of a block id: blocks that share a W tile agree mod 8 -> same XCD (round-robin dispatch).
 __device__ __forceinline__ void tf_block_map(int bid, int n_tiles, int n_rb, int& nt, int& rb) {
   const int n8 = n_tiles & ~7;
@@ -83,10 +95,10 @@ __device__ __forceinline__ void tf_block_map(int bid, int n_tiles, int n_rb, int
 }
 
 // W tile [BN rows x K] -> LDS image by LDS-DMA; image chunk p = (row, phys) holds logical chunk phys ^ (row & 15).
-__device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0, int BN, int wave, int lane) {
+__device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0, int BN, int wave, int lane, int nw) {
   const int cpr = a.K >> 3;                    // 16-B chunks per row
   const int total = (BN * cpr) >> 6;           // wave instructions (64 chunks each)
-  for (int ii = wave; ii < total; ii += 4) {
+  for (int ii = wave; ii < total; ii += nw) {
     const int p = ii * 64 + lane;
     const int row = p / cpr, phys = p - row * cpr;
     const int nrow = min(n0 + row, a.N - 1);   // rows past N (odd head widths) re-read the last row; never stored
@@ -96,23 +108,25 @@ __device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0,
 }
 
 // ---- A operand producers --------------------------------------------------------------------------------------------
-// thread t: row t>>3, 8 threads per row, float4 at columns 4*(t8 + 8 i).
+// thread t: row t / TPR, TPR = 2 NW threads per row, float4 at columns 4*(t8 + TPR i).
 // The GEMM consumes z = (y - mean) * rstd: gamma is folded into the packed weight columns and beta W^T into the packed bias
 // (LN(y) W^T + b = z (W . gamma)^T + (b + W beta)), so the 32 row groups do not each re-read gamma and beta.  The fp32 side
 // output x = z * gamma + beta (the residual operand of a later launch) needs them only for this block's BN columns.
-template <typename T, int KD, int BN>
+template <typename T, int KD, int BN, int NW>
 __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, int nt, int tid) {
-  constexpr int NI = KD / 32;
-  const int row = tid >> 3, t8 = tid & 7;
+  constexpr int TPR = 2 * NW;                    // threads per row (32 rows x TPR = 64 NW threads)
+  constexpr int NI = KD / (4 * TPR);
+  const int row = tid / TPR, t8 = tid % TPR;
   const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
   const float* src = (const float*)a.A + (size_t)grow * a.lda;
   float4 x[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) x[i] = *(const float4*)(src + 4 * (t8 + 8 * i));
+  for (int i = 0; i < NI; ++i) x[i] = *(const float4*)(src + 4 * (t8 + TPR * i));
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
   const float mean = s * (1.0f / KD);
   float v = 0.f;
 #pragma unroll
@@ -120,13 +134,14 @@ __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, 
     x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
     v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
   }
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
   const float rstd = rsqrtf(v * (1.0f / KD) + a.eps);
   const bool emit = a.xout != nullptr && row < a.rpb && rb * a.rpb + row < a.M;
   float* xo = a.xout + (size_t)grow * KD;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int c4 = t8 + 8 * i;
+    const int c4 = t8 + TPR * i;
     float4 z;
     z.x = x[i].x * rstd; z.y = x[i].y * rstd; z.z = x[i].z * rstd; z.w = x[i].w * rstd;
     if (emit && (4 * c4) / BN == nt) {            // this block's BN columns of the fp32 side output
@@ -138,21 +153,22 @@ __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, 
   }
 }
 
-template <typename T>
+template <typename T, int NW>
 __device__ __forceinline__ void tf_pro_f32(const TfArgs& a, char* a_img, int rb, int tid) {
-  const int row = tid >> 3, t8 = tid & 7;
+  constexpr int TPR = 2 * NW;
+  const int row = tid / TPR, t8 = tid % TPR;
   const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
   const float* src = (const float*)a.A + (size_t)grow * a.lda;
-  const int ni = a.K >> 5;
+  const int ni = a.K / (4 * TPR);
   for (int i0 = 0; i0 < ni; i0 += 8) {
     float4 x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i0 + i < ni) x[i] = *(const float4*)(src + 4 * (t8 + 8 * (i0 + i)));
+      if (i0 + i < ni) x[i] = *(const float4*)(src + 4 * (t8 + TPR * (i0 + i)));
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i0 + i < ni) {
-        const int c4 = t8 + 8 * (i0 + i);
+        const int c4 = t8 + TPR * (i0 + i);
         *(uint2*)(a_img + row * (a.K * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
             make_uint2(pack2<T>(x[i].x, x[i].y), pack2<T>(x[i].z, x[i].w));
       }
@@ -160,10 +176,10 @@ __device__ __forceinline__ void tf_pro_f32(const TfArgs& a, char* a_img, int rb,
 }
 
 // 16-bit A rows by LDS-DMA (same image as W)
-__device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, int wave, int lane) {
+__device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, int wave, int lane, int nw) {
   const int cpr = a.K >> 3;
   const int total = (TF_BM * cpr) >> 6;
-  for (int ii = wave; ii < total; ii += 4) {
+  for (int ii = wave; ii < total; ii += nw) {
     const int p = ii * 64 + lane;
     const int row = p / cpr, phys = p - row * cpr;
     const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
@@ -175,11 +191,11 @@ __device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, 
 // V rows of the block's clips -> LDS image [vrows][D] by LDS-DMA: vrows = (cpb-1)*Tk + 16*NKT, NKT = key tiles (Tk <= 16: keys
 // 16..31 of the 32-key P V step are fed as zeros, no LDS rows); rows past the data repeat the last key (finite values under
 // a zero probability).
-__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int vrows, int wave, int lane) {
+__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int vrows, int wave, int lane, int nw) {
   const int cpr = a.K >> 3;
   const int total = (vrows * cpr + 63) >> 6;
   const int c0 = rb * a.cpb;
-  for (int ii = wave; ii < total; ii += 4) {
+  for (int ii = wave; ii < total; ii += nw) {
     const int p = min(ii * 64 + lane, vrows * cpr - 1);
     const int row = p / cpr, phys = p - row * cpr;
     const int ci = min(row / a.Tk, a.cpb - 1);
@@ -194,37 +210,34 @@ __device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb,
 // K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
 // of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
 // operand of the out_proj GEMM.
-template <int DH, int QT, int NKT>
+template <int DH, int QT, int NKT, int NW>
 struct TfAttnFrags {
-  static constexpr int KK = DH / 32, PB = 4 / QT;
+  static constexpr int KK = DH / 32, PB = (16 / NW) / QT;     // (clip, head) pairs in flight per wave
   uint4 kf[PB][NKT][KK], qf[PB][QT][KK];
   uint32_t livebits[2];
 };
 
-// K / Q fragments of this wave's first PB (clip, head) pairs + the liveness of this lane's keys: plain global loads, issued
-// together with the LDS-DMA of the V and W images so that one round trip covers all of them.
-template <int DH, int QT, int NKT>
-__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT>& f, int rb, int p0, int lane) {
-  constexpr int KK = DH / 32, PB = 4 / QT;
-  const int r = lane & 15, q = lane >> 4;
+// K / Q fragments of this wave's first PB (clip, head) pairs (fragment-major buffers: one coalesced 1-KiB load each) + the
+// liveness of this lane's keys: plain global loads, issued together with the LDS-DMA of the V and W images so that one round
+// trip covers all of them.  Token rows >= T (or Tk) of a tile were never written: they only reach masked scores / unused rows.
+template <int DH, int QT, int NKT, int NW>
+__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, int rb, int p0, int lane) {
+  constexpr int KK = DH / 32, PB = (16 / NW) / QT;
   const int c0 = rb * a.cpb, npairs = a.cpb * a.H;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int p = min(p0 + i, npairs - 1);
     const int ci = p / a.H, h = p - ci * a.H;
     const int clip = min(c0 + ci, a.B - 1);
+    const size_t rec = (size_t)(clip * a.H + h) * 2 * KK;       // 1-KiB records of this (clip, head): [token tile][kk]
 #pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
-      const uint16_t* kr = a.k + ((size_t)clip * a.Tk + min(16 * nt + r, a.Tk - 1)) * a.ldk + h * DH + 8 * q;
+    for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(kr + 32 * kk);
-    }
+      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(a.k + (rec + nt * KK + kk) * 512 + lane * 8);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      const uint16_t* qr = a.q + ((size_t)clip * a.T + min(16 * qt + r, a.T - 1)) * a.ldq + h * DH + 8 * q;
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(qr + 32 * kk);
-    }
+      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(a.q + (rec + qt * KK + kk) * 512 + lane * 8);
   }
 }
 
@@ -257,17 +270,17 @@ __device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebit
 // K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
 // of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
 // operand of the out_proj GEMM.
-template <typename T, int DH, int QT, int NKT>
-__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT>& f, char* a_img, const char* v_img, int rb, int wave,
+template <typename T, int DH, int QT, int NKT, int NW>
+__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, char* a_img, const char* v_img, int rb, int wave,
                                             int lane) {
-  constexpr int KK = DH / 32, DT = DH / 16, PB = 4 / QT;
+  constexpr int KK = DH / 32, DT = DH / 16, PB = (16 / NW) / QT;
   const int r = lane & 15, q = lane >> 4;
   const int npairs = a.cpb * a.H;
   const int rowb = a.K * 2;
   const float c2 = a.scale * 1.4426950408889634f;
   const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
-  for (int p0 = wave * PB; p0 < npairs; p0 += 4 * PB) {
-    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
+  for (int p0 = wave * PB; p0 < npairs; p0 += NW * PB) {
+    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT, NW>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const bool valid = p0 + i < npairs;           // no early exit: the PB chains are independent and get interleaved
@@ -337,8 +350,10 @@ __device__ __forceinline__ uint32_t tf_lds_addr(const char* p) { return (uint32_
 
 // ---- epilogue: one lane's 4 consecutive columns of one row -------------------------------------------------------------
 // pre_added: bias (and residual) are already inside v (tf_gemm_body seeds the accumulators with them)
+// frag_dst: (EPI_ACT16) where this lane's 4 columns go in a fragment-major side buffer, or nullptr for the row-major output
 template <typename T, int EPI>
-__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v, bool pre_added = false) {
+__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v, bool pre_added = false,
+                                            uint16_t* frag_dst = nullptr) {
   if (col >= a.N) return;
   if (col + 3 < a.N) {
     if (!pre_added) {
@@ -350,9 +365,13 @@ __device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, 
       }
     }
     if (EPI == EPI_ACT16) {
-      *(uint2*)((uint16_t*)a.out + (size_t)grow * a.ldo + col) =
-          make_uint2(pack2<T>(apply_act_rt(v[0], a.act), apply_act_rt(v[1], a.act)),
-                     pack2<T>(apply_act_rt(v[2], a.act), apply_act_rt(v[3], a.act)));
+      const uint2 o = make_uint2(pack2<T>(apply_act_rt(v[0], a.act), apply_act_rt(v[1], a.act)),
+                                 pack2<T>(apply_act_rt(v[2], a.act), apply_act_rt(v[3], a.act)));
+      if (frag_dst != nullptr) {                    // q / k columns: fragment-major side buffer
+        *(uint2*)frag_dst = o;
+      } else {
+        *(uint2*)((uint16_t*)a.out + (size_t)grow * a.ldo + col) = o;
+      }
     } else if ((a.ldo & 3) == 0) {
       *(float4*)((float*)a.out + (size_t)grow * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
@@ -370,41 +389,38 @@ __device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, 
 }
 
 // ---- single-shot K kernel ----------------------------------------------------------------------------------------------
-// LDS: [A image 32 x K][W image BN x K][k-half exchange 2 x NTN x 1 KiB][V image (PRO_ATTN)]
+// LDS: [A image 32 x K][W image BN x K][V image (PRO_ATTN)]; the K-slice exchange of the accumulators re-uses the A image
 // Every global access of the prologue (A rows / LayerNorm parameters / K, Q fragments / mask bytes / the LDS-DMA of the W
 // and V images) is issued before the first wait, so a workgroup pays ONE memory round trip before its MFMAs.
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT>
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT, int NW>
 __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_smem) {
   constexpr int NTN = BN / 16;
   constexpr int ROWB = KD * 2;
-  constexpr int KSTEPS = KD / 64;                // 32-wide k-steps per K half
+  constexpr int KSP = NW / 2;                    // K slices (waves = 2 row tiles x KSP K slices)
+  constexpr int KSTEPS = KD / 32 / KSP;          // 32-wide k-steps per slice
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int nt, rb;
   tf_block_map(bid, a.n_tiles, a.n_rb, nt, rb);
   char* a_img = tf_smem;
   char* w_img = a_img + TF_BM * ROWB;
-  char* red = w_img + BN * ROWB;
-  char* v_img = red + 2 * NTN * 1024;
+  char* v_img = w_img + BN * ROWB;
+  char* red = a_img;                             // K-slice exchange re-uses the A image once every wave is past its MFMAs
   const int n0 = nt * BN;
 
   if constexpr (PRO == PRO_ATTN) {
-    TfAttnFrags<DH, QT, NKT> fr;
-    tf_attn_load<DH, QT, NKT>(a, fr, rb, wave * (4 / QT), lane);
+    TfAttnFrags<DH, QT, NKT, NW> fr;
+    tf_attn_load<DH, QT, NKT, NW>(a, fr, rb, wave * ((16 / NW) / QT), lane);
     tf_attn_live(a, fr.livebits, rb, lane);
-    tf_stage_v(a, v_img, rb, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane);
-    tf_stage_w(a, w_img, n0, BN, wave, lane);
+    tf_stage_v(a, v_img, rb, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane, NW);
+    tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                             // V (and W) images complete
-#ifndef TF_SKIP_ATTN
-    tf_pro_attn<T, DH, QT, NKT>(a, fr, a_img, v_img, rb, wave, lane);
-#else
-    asm volatile("" ::"v"(fr.kf[0][0][0].x), "v"(fr.qf[0][0][0].x), "v"(fr.livebits[0]));
-#endif
+    tf_pro_attn<T, DH, QT, NKT, NW>(a, fr, a_img, v_img, rb, wave, lane);
   } else {
-    tf_stage_w(a, w_img, n0, BN, wave, lane);
-    if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane);
-    if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN>(a, a_img, rb, nt, tid);
-    if constexpr (PRO == PRO_F32) tf_pro_f32<T>(a, a_img, rb, tid);
+    tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
+    if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane, NW);
+    if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN, NW>(a, a_img, rb, nt, tid);
+    if constexpr (PRO == PRO_F32) tf_pro_f32<T, NW>(a, a_img, rb, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
@@ -418,7 +434,7 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
   const int grow_e = rb * a.rpb + arow;
   const bool store_e = ks == 0 && arow < a.rpb && grow_e < a.M;
   if (store_e && a.N % 4 == 0) {
-    // the epilogue's bias (+ residual) operands ride under the MFMA loop: start the K-half-0 accumulators from them
+    // the epilogue's bias (+ residual) operands ride under the MFMA loop: start the K-slice-0 accumulators from them
 #pragma unroll
     for (int n = 0; n < NTN; ++n) {
       const int col = n0 + 16 * n + 4 * q;
@@ -453,36 +469,53 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
 #pragma unroll
       for (int n = 0; n < NTN; ++n) acc[n] = T::mfma16(wf[kk][n], af[kk], acc[n]);
   }
-  if (ks == 1) {
+  __syncthreads();
+  if (ks > 0) {
 #pragma unroll
-    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16) = acc[n];
+    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((((ks - 1) * 2 + rt) * NTN + n) * 64 + lane) * 16) = acc[n];
   }
   __syncthreads();
   if (ks == 0) {
     const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
     if (lrow < a.rpb && grow < a.M) {
+      int fclip = 0, ft = 0;
+      if (EPI == EPI_ACT16 && a.frag_D > 0) {          // token coordinates of this lane's row: once, not per column tile
+        fclip = grow / a.frag_T;
+        ft = grow - fclip * a.frag_T;
+      }
 #pragma unroll
       for (int n = 0; n < NTN; ++n) {
-        const f32x4 o = *(const f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16);
-        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o, pre_added);
+        f32x4 o = acc[n];
+#pragma unroll
+        for (int s2 = 0; s2 < KSP - 1; ++s2) o += *(const f32x4*)(red + (((s2 * 2 + rt) * NTN + n) * 64 + lane) * 16);
+        uint16_t* fdst = nullptr;
+        if (EPI == EPI_ACT16 && a.frag_D > 0) {
+          const int c0 = __builtin_amdgcn_readfirstlane(n0 + 16 * n);      // wave-uniform: scalar divisions
+          const int fi = c0 / a.frag_D;
+          if (fi < 2 && a.frag[fi] != nullptr) {      // a 16-column MFMA tile never straddles a head (head_dim % 16 == 0)
+            const int c = c0 - fi * a.frag_D, head = c / a.frag_DH, d = c - head * a.frag_DH + 4 * q;
+            fdst = a.frag[fi] + tf_frag_off(fclip, head, ft, d, a.frag_H, a.frag_DH);
+          }
+        }
+        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, o, pre_added, fdst);
       }
     }
   }
 }
 
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT>
-__global__ void __launch_bounds__(TF_NTH) tf_gemm_kernel(const TfArgs a) {
+template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT, int NW>
+__global__ void __launch_bounds__(64 * NW) tf_gemm_kernel(const TfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char tf_smem[];
-  tf_gemm_body<T, BN, PRO, EPI, KD, DH, QT, NKT>(a, blockIdx.x, tf_smem);
+  tf_gemm_body<T, BN, PRO, EPI, KD, DH, QT, NKT, NW>(a, blockIdx.x, tf_smem);
 }
 
 // Two independent problems in one launch: a layer's qkv projection (raw tokens or LayerNorm prologue) + the K|V projection of
 // the raw motion tokens for that layer's cross attention: neither depends on the other, so the K|V GEMM costs no launch of its own.
-template <typename T, int BN, int PRO, int EPI, int KD>
-__global__ void __launch_bounds__(TF_NTH) tf_gemm_pair_kernel(const TfArgs a, const TfArgs b, int blocks_a) {
+template <typename T, int BN, int PRO, int EPI, int KD, int NW>
+__global__ void __launch_bounds__(64 * NW) tf_gemm_pair_kernel(const TfArgs a, const TfArgs b, int blocks_a) {
   extern __shared__ __attribute__((aligned(16))) char tf_smem[];
-  if ((int)blockIdx.x < blocks_a) tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1>(a, blockIdx.x, tf_smem);
-  else tf_gemm_body<T, BN, PRO_F32, EPI, KD, 64, 1, 1>(b, blockIdx.x - blocks_a, tf_smem);      // b: always raw fp32 rows
+  if ((int)blockIdx.x < blocks_a) tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1, NW>(a, blockIdx.x, tf_smem);
+  else tf_gemm_body<T, BN, PRO_F32, EPI, KD, 64, 1, 1, NW>(b, blockIdx.x - blocks_a, tf_smem);      // b: always raw fp32 rows
 }
 
 // ---- chunked-K kernel (FFN second linear): A 16-bit and W both by LDS-DMA through an NST-deep ring -----------------------
@@ -675,9 +708,11 @@ __global__ void __launch_bounds__(256) tf_fold_ln_kernel(const float* __restrict
 // ---- host side ---------------------------------------------------------------------------------------------------------
 constexpr size_t TF_LDS_MAX = 160 * 1024;
 
+constexpr int TF_NW = 8;       // waves per workgroup of the single-shot kernels (2 row tiles x 4 K slices)
+
 template <int BN, int PRO, int KD, int NKT>
 constexpr size_t tf_lds_bytes(int cpb, int Tk) {
-  return (size_t)(TF_BM + BN) * KD * 2 + 2 * (BN / 16) * 1024 +
+  return (size_t)(TF_BM + BN) * KD * 2 +
          (PRO == PRO_ATTN ? (size_t)((cpb - 1) * Tk + 16 * NKT) * KD * 2 + 1024 : 0);    // + one LDS-DMA piece of slack
 }
 
@@ -695,12 +730,13 @@ template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT 
 int tf_launch(TfArgs& a, hipStream_t s) {
   const size_t lds = tf_lds_bytes<BN, PRO, KD, NKT>(a.cpb, a.Tk);
   if (lds > TF_LDS_MAX || a.K != KD) return VMC_E_SHAPE;
+  if ((TF_NW / 2 - 1) * 2 * (BN / 16) * 1024 > TF_BM * KD * 2) return VMC_E_SHAPE;      // K-slice exchange must fit the A image
   a.n_tiles = (a.N + BN - 1) / BN;
   a.n_rb = (a.M + a.rpb - 1) / a.rpb;
-  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT, NKT>;
+  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT, NKT, TF_NW>;
   static bool attr_done = false;                // per instantiation
   if (int rc = tf_set_lds(kern, attr_done)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(64 * TF_NW), lds, s, a);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -711,11 +747,11 @@ int tf_launch_pair(TfArgs& a, TfArgs& b, hipStream_t s) {
   if (lds > TF_LDS_MAX || a.K != KD || b.K != KD) return VMC_E_SHAPE;
   a.n_tiles = (a.N + BN - 1) / BN; a.n_rb = (a.M + a.rpb - 1) / a.rpb;
   b.n_tiles = (b.N + BN - 1) / BN; b.n_rb = (b.M + b.rpb - 1) / b.rpb;
-  auto kern = tf_gemm_pair_kernel<T, BN, PRO, EPI, KD>;
+  auto kern = tf_gemm_pair_kernel<T, BN, PRO, EPI, KD, TF_NW>;
   static bool attr_done = false;
   if (int rc = tf_set_lds(kern, attr_done)) return rc;
   const int na = a.n_tiles * a.n_rb;
-  hipLaunchKernelGGL(kern, dim3(na + b.n_tiles * b.n_rb), dim3(TF_NTH), lds, s, a, b, na);
+  hipLaunchKernelGGL(kern, dim3(na + b.n_tiles * b.n_rb), dim3(64 * TF_NW), lds, s, a, b, na);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -737,7 +773,7 @@ int tf_launch_ring(TfArgs& a, hipStream_t s) {
 // Output-column tile.  A workgroup's cost is one memory round trip plus (32 A rows + BN W rows) x K bytes at the ~70 GB/s one
 // CU pulls from L2, whatever BN is; what BN decides is how many workgroups there are.  Take the narrowest tile (most CUs
 // streaming W) whose grid still fits one resident round (2 workgroups per CU while the LDS footprint allows, else 1).
-inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn) {
+inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn, int vrows = 48) {
   const int n_rb = (M + rpb - 1) / rpb;
   const int cands[4] = {16, 32, 48, 64};
   int best = 16;
@@ -745,7 +781,7 @@ inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn) {
     const int bn = cands[i];
     if (N % bn && !(N < bn)) continue;
     if (attn && bn > 32) break;
-    const size_t lds = (size_t)(TF_BM + bn) * K * 2 + 2048 + (attn ? (size_t)48 * K * 2 : 0);
+    const size_t lds = (size_t)(TF_BM + bn) * K * 2 + (attn ? (size_t)vrows * K * 2 + 1024 : 0);
     if (lds > TF_LDS_MAX) break;
     best = bn;
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -845,10 +881,13 @@ extern "C" long long vmc_tfam_pack_offset(int slot, int layer, int D, int ff, in
 }
 
 // workspace: [y f32 M*D][xa f32 M*D][xb f32 M*D][qkv16 M*3D][q16 M*D][h16 M*ff][kv16 Mk*L*2D][pool16 B*D][g16 B*D/2]
+//            [q frag][self-k frag][cross-k frag x L]   (fragment-major, tf_frag_off; the row-major q / k columns stay unused)
 namespace {
 struct TfWs {
   float *y, *xa, *xb;
   uint16_t *qkv, *q, *h, *kv, *pool, *g;
+  uint16_t *qf, *kf, *kxf;      // fragment-major q, self k, and (per layer) cross k
+  size_t kxf_stride;            // elements between two layers' cross-k buffers
   size_t bytes;
 };
 inline TfWs tf_ws(void* base, const TfDims& d) {
@@ -866,6 +905,11 @@ inline TfWs tf_ws(void* base, const TfDims& d) {
   w.kv = (uint16_t*)(p + o); o += al(Mk * d.L * 2 * d.D * 2);
   w.pool = (uint16_t*)(p + o); o += al((size_t)d.B * d.D * 2);
   w.g = (uint16_t*)(p + o); o += al((size_t)d.B * (d.D / 2) * 2);
+  const int H = d.H > 0 ? d.H : 8, dh = d.D / H;
+  const size_t fe = tf_frag_elems(d.B, H, dh);
+  w.qf = (uint16_t*)(p + o); o += al(fe * 2);
+  w.kf = (uint16_t*)(p + o); o += al(fe * 2);
+  w.kxf = (uint16_t*)(p + o); w.kxf_stride = al(fe * 2) / 2; o += (d.has_cross ? d.L : 0) * al(fe * 2);
   w.bytes = o;
   return w;
 }
@@ -881,20 +925,16 @@ int tf_gemm_k(TfArgs& a, int bn, hipStream_t s) {
   }
 }
 
-inline TfArgs tf_kv_args(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w) {
-  TfArgs a = {};
-  a.A = motion; a.lda = d.D;
-  a.M = d.B * d.Tk; a.N = d.L * 2 * d.D; a.K = d.D; a.rpb = 32;
-  a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_KV_ALL, 0, d.D, d.ff, d.L, d.C); a.ldw = d.D;
-  a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, 0, d.D, d.ff, d.L, d.C);
-  a.out = w.kv; a.ldo = a.N; a.act = VMC_ACT_NONE;
-  return a;
-}
+inline TfArgs tf_kv_layer_args(const float* motion, const uint16_t* wp, const float* pp, int layer, const TfDims& d, const TfWs& w);
 
+// stand-alone K|V projection of every layer (vmc_tfam_kv_fwd; vmc_tfam_forward pairs each layer's with its qkv launch instead)
 template <typename T>
 int tf_kv_impl(const float* motion, const uint16_t* wp, const float* pp, const TfDims& d, const TfWs& w, hipStream_t s) {
-  TfArgs a = tf_kv_args(motion, wp, pp, d, w);
-  return tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N, a.rpb, a.K, false), s);
+  for (int l = 0; l < d.L; ++l) {
+    TfArgs a = tf_kv_layer_args(motion, wp, pp, l, d, w);
+    if (int rc = tf_gemm_k<T, PRO_F32, EPI_ACT16>(a, tf_pick_bn(a.M, a.N, a.rpb, a.K, false), s)) return rc;
+  }
+  return 0;
 }
 
 // a layer's qkv projection and its cross-attention K|V projection in ONE launch
@@ -913,6 +953,8 @@ inline TfArgs tf_kv_layer_args(const float* motion, const uint16_t* wp, const fl
   a.W = wp + vmc_tfam_pack_offset(VMC_TFAM_W_KV_ALL, layer, d.D, d.ff, d.L, d.C); a.ldw = d.D;
   a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, layer, d.D, d.ff, d.L, d.C);
   a.out = w.kv + (size_t)layer * 2 * d.D; a.ldo = d.L * 2 * d.D; a.act = VMC_ACT_NONE;
+  a.frag[0] = w.kxf + (size_t)layer * w.kxf_stride; a.frag[1] = nullptr;      // K columns fragment-major, V columns row-major
+  a.frag_D = d.D; a.frag_T = d.Tk; a.frag_H = d.H; a.frag_DH = d.D / d.H;
   return a;
 }
 
@@ -922,7 +964,7 @@ inline int tf_pick_bn_pair(int Ma, int Na, int rpba, int Mb, int Nb, int K) {
   int best = 64;
   for (int i = 0; i < 4; ++i) {
     const int bn = cands[i];
-    if ((Na % bn) || (Nb % bn) || (size_t)(TF_BM + bn) * K * 2 + 8192 > TF_LDS_MAX) continue;
+    if ((Na % bn) || (Nb % bn) || (size_t)(TF_BM + bn) * K * 2 > TF_LDS_MAX) continue;
     best = bn;
     const long blocks = (long)(Na / bn) * ((Ma + rpba - 1) / rpba) + (long)(Nb / bn) * ((Mb + 31) / 32);
     if (blocks <= 256) break;
@@ -946,6 +988,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.M = M; a.N = 3 * D; a.K = D; a.rpb = rpb;
     a.W = W(VMC_TFAM_W_SELF_IN); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_IN_B, layer);
     a.out = w.qkv; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
+    a.frag[0] = w.qf; a.frag[1] = w.kf; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;    // V columns stay row-major
     const bool pair = merge_kv_motion != nullptr && d.has_cross;
     TfArgs b = {};
     int bn = tf_pick_bn(M, a.N, rpb, D, false);
@@ -965,11 +1008,12 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     }
     if (rc) return rc;
   }
-  const int bn_attn = tf_pick_bn(M, D, rpb, D, true);
+  const int bn_attn = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.T + (d.T > 16 ? 32 : 16));
+  const int bn_cross = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.Tk + (d.Tk > 16 ? 32 : 16));
   {  // 2: y = resid + selfattn(qkv) Wo^T + b
     TfArgs a = {};
     a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
-    a.q = w.qkv; a.k = w.qkv + D; a.v = w.qkv + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D;
+    a.q = w.qf; a.k = w.kf; a.v = w.qkv + 2 * D; a.ldv = 3 * D;
     a.kmask = mask; a.T = d.T; a.Tk = d.T; a.H = d.H; a.B = d.B; a.scale = scale;
     a.W = W(VMC_TFAM_W_SELF_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_OUT_B, layer);
     a.resid = resid; a.ldres = D; a.out = w.y; a.ldo = D;
@@ -984,17 +1028,18 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
       a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xb;
       a.W = W(VMC_TFAM_W_CROSS_Q); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_Q_B, layer);
       a.out = w.q; a.ldo = D; a.act = VMC_ACT_NONE;
+      a.frag[0] = w.qf; a.frag[1] = nullptr; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;
       if ((rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, tf_pick_bn(M, a.N, rpb, D, false), s))) return rc;
     }
     {  // 4: y = xb + crossattn(q, K_l, V_l) Wo^T + b
       TfArgs a = {};
       a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
-      a.q = w.q; a.ldq = D;
-      a.k = w.kv + (size_t)layer * 2 * D; a.v = a.k + D; a.ldk = a.ldv = d.L * 2 * D;
+      a.q = w.qf;
+      a.k = w.kxf + (size_t)layer * w.kxf_stride; a.v = w.kv + (size_t)layer * 2 * D + D; a.ldv = d.L * 2 * D;
       a.kmask = mask_kv; a.T = d.T; a.Tk = d.Tk; a.H = d.H; a.B = d.B; a.scale = scale;
       a.W = W(VMC_TFAM_W_CROSS_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_OUT_B, layer);
       a.resid = w.xb; a.ldres = D; a.out = w.y; a.ldo = D;
-      if ((rc = (D == 768 ? tf_dispatch_attn<T, 768>(a, bn_attn, dh, s) : tf_dispatch_attn<T, 512>(a, bn_attn, dh, s)))) return rc;
+      if ((rc = (D == 768 ? tf_dispatch_attn<T, 768>(a, bn_cross, dh, s) : tf_dispatch_attn<T, 512>(a, bn_cross, dh, s)))) return rc;
     }
     ln_g = P(VMC_TFAM_P_NORM_CROSS, layer);
   }
@@ -1065,7 +1110,7 @@ extern "C" int vmc_tfam_fold_layernorm(const float* W, const float* bias, const 
 }
 
 extern "C" size_t vmc_tfam_workspace_bytes(int B, int T, int Tk, int D, int ff, int L, int C, int has_cross) {
-  TfDims d = {B, T, Tk, D, 8, ff, L, C, has_cross};
+  TfDims d = {B, T, Tk, D, 8, ff, L, C, has_cross};      // the head count does not change any size (frag buffers: B * D * 32 elements)
   return tf_ws(nullptr, d).bytes;
 }
 
