@@ -231,6 +231,29 @@ def tfam_forward_block(dev, rank, cdt, batches=(8, 16, 64), iters=200):
                           "mfma_frac": round(B / t_res * flops_clip / (MFMA_PEAK_TFLOPS * 1e12), 4)}
             del g
         m.fused_inference = True
+        if B == 8:
+            # throughput with several independent batches in flight (an evaluation loop: batches do not depend on each other):
+            # one graph + one scratch slot per stream, replayed round-robin; a launch's fixed ~4 us overlaps the other streams' work
+            for nfl in (2, 4):
+                streams = [torch.cuda.Stream() for _ in range(nfl)]
+                graphs = []
+                for i, st in enumerate(streams):
+                    m.fused_slot = i
+                    with torch.cuda.stream(st):
+                        graphs.append(GraphedCallable(fwd, rgb, mot, mk, mk))
+                m.fused_slot = 0
+                torch.cuda.synchronize()
+                reps = max(20, iters // nfl)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    for st, g in zip(streams, graphs):
+                        with torch.cuda.stream(st):
+                            g.replay()
+                torch.cuda.synchronize()
+                t_in = (time.perf_counter() - t0) / (reps * nfl)
+                row[f"fused_chain_{nfl}_in_flight"] = {"us_per_forward": round(t_in * 1e6, 2), "clips_per_s": round(B / t_in, 1),
+                                                       "note": "weights served by L2 / Infinity Cache across the concurrent forwards"}
+                del graphs
         row["bytes_fwd"] = tfam_hbm_bytes(B)[0]
         out[f"B{B}"] = row
     return {"bound": "hbm (B <~ 20) / mfma", "peak": 8000.0, "unit": "GB/s", "launches_per_forward": 1 + 6 * 4 + 3,

@@ -320,7 +320,14 @@ def test_tfam_graphed_eval_matches_eager_and_is_reused():
             with torch.no_grad():
                 ref = m(batch["embeddings"].cuda(), batch["flow_embeddings"].cuda(), mask_rgb=batch["mask_rgb"].cuda(), mask_flow=batch["mask_flow"].cuda())
             assert torch.equal(gf(batch), ref)
-        assert 1 <= len(gf._graphs) <= max_graphs
+        assert 1 <= len(gf._graphs) <= max_graphs * len(gf._streams)      # one graph per (slot, shape)
+        # two batches in flight (launch k+1 before consuming k): same logits, same order
+        bs = [collate_fn_pad([ds[i] for i in range(s, s + 8)]) for s in range(0, 64, 8)]
+        with torch.no_grad():
+            refs = [m(b["embeddings"].cuda(), b["flow_embeddings"].cuda(), mask_rgb=b["mask_rgb"].cuda(), mask_flow=b["mask_flow"].cuda()) for b in bs]
+        got = list(GraphedEvalForward(m, cfg).pipelined(iter(bs)))
+        assert len(got) == len(bs) and all(g_[0] is b for g_, b in zip(got, bs))
+        assert all(torch.equal(g_[1], r) for g_, r in zip(got, refs))
     mAP_g, _ = ModelTester(m, fixed, cfg).evaluate()
     cfg.use_graphs = False
     mAP_e, _ = ModelTester(m, fixed, cfg).evaluate()

@@ -35,7 +35,7 @@ def test_fused_chain_is_taken_and_matches_reference(golden, c, dtype, monkeypatc
     m = _tfam(c, dtype)
     calls = []
     orig = tf.TfamPack.forward
-    monkeypatch.setattr(tf.TfamPack, "forward", lambda self, *a: calls.append(1) or orig(self, *a))
+    monkeypatch.setattr(tf.TfamPack, "forward", lambda self, *a, **k: calls.append(1) or orig(self, *a, **k))
     rgb, mot, mr, mf = mg.tfam_inputs(c)
     with torch.no_grad():
         y = m(rgb.cuda(), mot.cuda(), mask_rgb=mr.cuda(), mask_flow=mf.cuda()).cpu()

@@ -260,7 +260,7 @@ class AMO_CLIP(nn.Module):
         if x.shape[-1] != self.d_model or not tf.supported(self, x.shape[0], x.shape[1], motion.shape[1] if cross else 0, cross):
             return None
         pack = tf.get_pack(self, dt16).refresh()
-        return pack.forward(f32(x), f32(motion) if cross else None, m, m_kv, cross)
+        return pack.forward(f32(x), f32(motion) if cross else None, m, m_kv, cross, slot=getattr(self, "fused_slot", 0))
 
     def forward(self, rgb_emb, motion_emb, mask_rgb=None, mask_flow=None):
         dt16, D = self.compute_dtype, self.d_model

@@ -128,8 +128,10 @@ class TfamPack:
         self._key = self._state_key()
         return self
 
-    def workspace(self, B, T, Tk, has_cross):
-        key = (B, T, Tk, has_cross)
+    def workspace(self, B, T, Tk, has_cross, slot=0):
+        """Scratch of one forward.  `slot`: forwards that may be in flight at the same time (several streams / graphs over
+        independent batches) need a scratch buffer each."""
+        key = (B, T, Tk, has_cross, slot)
         ws = self._ws.get(key)
         if ws is None:
             n = lib.vmc_tfam_workspace_bytes(B, T, Tk, self.D, self.ff, self.L, self.C, int(has_cross))
@@ -138,11 +140,11 @@ class TfamPack:
             ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.wpack.device)
         return ws
 
-    def forward(self, x, motion, mask, mask_kv, has_cross):
+    def forward(self, x, motion, mask, mask_kv, has_cross, slot=0):
         """x [B,T,D] fp32 tokens, motion [B,Tk,D] fp32 (cross mode) or None, masks uint8 [B,T] / [B,Tk] or None."""
         B, T, D = x.shape
         Tk = motion.shape[1] if has_cross else 0
-        ws = self.workspace(B, T, Tk, has_cross)
+        ws = self.workspace(B, T, Tk, has_cross, slot)
         logits = torch.empty((B, self.C), dtype=torch.float32, device=x.device)
         check(lib.vmc_tfam_forward(ptr(x), ptr(motion) if has_cross else None, ptr(mask), ptr(mask_kv) if has_cross else None,
                                    ptr(self.wpack), ptr(self.ppack), ptr(logits), ptr(ws), ws.numel(), B, T, Tk, D, self.H, self.ff,
