@@ -133,10 +133,6 @@ int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbi
  * one tile per workgroup, the tile rows of a small last partial round handed to the small-tile kernel in a second
  * launch), VMC_GEMM_NO_TAIL_SPLIT = the same without that split.  Results are identical bit for bit across them. */
 enum { VMC_GEMM_TWOSTAGE = 0, VMC_GEMM_DEFAULT = 1, VMC_GEMM_NO_TAIL_SPLIT = 2, VMC_GEMM_VARIANTS = 3 };
-/* Epilogue options of the 8-phase kernel, OR-ed into `variant` (16-bit output, no residual): stage the C tile through LDS
- * and store whole 512-byte rows; non-temporal output stores. */
-enum { VMC_GEMM_FLAG_LDS_EPILOGUE = 0x10, VMC_GEMM_FLAG_NT_STORE = 0x20,
-       VMC_GEMM_FLAG_GC2 = 0x40, VMC_GEMM_FLAG_GC8 = 0x80, VMC_GEMM_FLAG_GC16 = 0xC0 /* column-group width of the tile walk (default 4) */ };
 int vmc_linear_variant(const void* A, const void* W, const float* bias, const void* res, void* C,
                        int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                        int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--variants", type=lambda x: int(x, 0), nargs="*", default=[1],
-                    help="vmc_linear_variant values: 0 two-stage, 1 default, 2 no tail split; | 0x10 LDS-staged epilogue, | 0x20 nt stores")
+                    help="vmc_linear_variant values: 0 two-stage, 1 default, 2 no tail split")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--act", type=int, default=0, help="0 none, 1 QuickGELU (adds a bias too)")
     ap.add_argument("--res32", action="store_true", help="fp32 residual in + fp32 out in place (out_proj / c_proj epilogue)")

@@ -330,7 +330,7 @@ extern "C" int vmc_linear_variant(const void* A, const void* W, const float* bia
                                   int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                                   int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,
                                   int dtype16, int variant, void* stream) {
-  if (variant < 0 || (variant & 0xF) >= VMC_GEMM_VARIANTS || (variant & ~0xFF)) return VMC_E_ARG;
+  if (variant < 0 || variant >= VMC_GEMM_VARIANTS) return VMC_E_ARG;
   return linear_impl(A, W, bias, res, C, nullptr, M, N, K, lda, ldw, ldc, ldres, 0, act, alpha, out_dtype, res_dtype, out_row_group,
                      res_row_mod, dtype16, variant, stream);
 }
@@ -368,7 +368,7 @@ static int linear_impl(const void* A, const void* W, const float* bias, const vo
   // variant VMC_GEMM_TWOSTAGE forces the two-stage kernels (A/B measurements through vmc_linear_variant).
   g.variant = variant;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if ((variant & 0xF) != VMC_GEMM_TWOSTAGE && t256 >= 192 && (K % 128) == 0) {
+  if (variant != VMC_GEMM_TWOSTAGE && t256 >= 192 && (K % 128) == 0) {
     // Round quantisation: T tiles on 256 CUs cost ceil(T/256) tile-times.  When the last, partial round holds only a few
     // tiles (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4; student ViT-B/32: 100 x 3 tiles ->
     // 44 tiles in a second round), the tile rows that do not fit the full rounds go to the small-tile kernels, which spread
@@ -378,7 +378,7 @@ static int linear_impl(const void* A, const void* W, const float* bias, const vo
     const int rounds = (int)(t256 / 256);
     const int main_rows = rounds > 0 ? (rounds * 256) / tn : 0;
     const long tail = (long)(tm - main_rows) * tn;              // tiles handed to the small-tile kernel
-    if ((variant & 0xF) != VMC_GEMM_NO_TAIL_SPLIT && !out_row_group && !res_row_mod && main_rows > 0 && main_rows < tm && t256 % 256 != 0 &&
+    if (variant != VMC_GEMM_NO_TAIL_SPLIT && !out_row_group && !res_row_mod && main_rows > 0 && main_rows < tm && t256 % 256 != 0 &&
         tail <= (rounds >= 2 ? 64 : 96)) {
       const int m_main = main_rows * 256;
       GemmArgs t = g;

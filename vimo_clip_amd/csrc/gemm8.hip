@@ -142,8 +142,7 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   int tm, tn;
   {
-    // VMC_GEMM_FLAG_GC_*: column-group width of the tile walk (A/B of the per-XCD L2 footprint); default 4
-    const int GC = (g.variant & 0xC0) == 0x40 ? 2 : (g.variant & 0xC0) == 0x80 ? 8 : (g.variant & 0xC0) == 0xC0 ? 16 : 4;
+    constexpr int GC = 4;      // widths 2 / 8 / 16 measured within 0.5 % (2-3 % slower on qkv): profiles/README.md round 2
     const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
     const int cg = tile / gsz;
     if (cg < nfull) {
@@ -229,9 +228,9 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
     }
     uint16_t* cbase = (uint16_t*)g.C + (size_t)(m0 + 64 * wm + r) * g.ldc + n0 + 32 * wn + 8 * q;
     uint16_t* zbase = g.zout ? (uint16_t*)g.zout + (size_t)(m0 + 64 * wm + r) * g.ldz + n0 + 32 * wn + 8 * q : nullptr;
-    const bool via_lds = (g.variant & VMC_GEMM_FLAG_LDS_EPILOGUE) != 0 && zbase == nullptr;
-    const bool nt_store = (g.variant & VMC_GEMM_FLAG_NT_STORE) != 0;
-    if (via_lds) __syncthreads();        // every wave is past its last fragment read: the 128 KiB of LDS are free
+    // Output stores are non-temporal: the tensor (400 .. 540 MB per ViT-L/14 launch) is larger than the Infinity Cache and is read
+    // next by another kernel; +1.2 .. 1.5 % on the qkv / c_fc shapes.  Staging the tile through LDS for whole-row stores was
+    // measured too and does not pay (profiles/README.md, round 2).
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -248,32 +247,9 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
                 make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
-          const uint4 o = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
-          if (via_lds) {
-            // C tile image [256 rows][32 chunks of 16 B], chunk XOR (row & 31): conflict-free for this write (16 rows x 4
-            // chunks per instruction) and for the row-contiguous read below
-            const int row = 128 * mh + 64 * wm + 16 * mt + r, chunk = 16 * nh + 4 * wn + q;
-            *(uint4*)(smem + row * 512 + ((chunk ^ (row & 31)) << 4)) = o;
-          } else if (nt_store) {
-            g8_nt_store(o, cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh);
-          } else {
-            *(uint4*)(cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh) = o;
-          }
+          g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
+                      cbase + (size_t)(128 * mh + 16 * mt) * g.ldc + 128 * nh);
         }
-    if (via_lds) {
-      // whole 512-B rows per half wave: every store instruction writes 8 full 128-B lines (the direct epilogue above writes
-      // 16 rows x 64 B per instruction: half lines, completed later by a neighbouring wave)
-      __syncthreads();
-      uint16_t* ctile = (uint16_t*)g.C + (size_t)m0 * g.ldc + n0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * wave + 2 * i + (lane >> 5), chunk = lane & 31;
-        const uint4 o = *(const uint4*)(smem + row * 512 + ((chunk ^ (row & 31)) << 4));
-        uint4* dst = (uint4*)(ctile + (size_t)row * g.ldc + 8 * chunk);
-        if (nt_store) g8_nt_store(o, (uint16_t*)dst);
-        else *dst = o;
-      }
-    }
     return;
   }
   // Interior tile accumulating into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of
