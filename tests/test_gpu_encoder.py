@@ -66,6 +66,23 @@ def test_encoder_vs_oracle_fresh_seed():
     assert (y - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["tiny14", "b32"])
+def test_last_block_on_class_rows_only_is_the_same_function(name):
+    """Only x[:, 0] of the last block reaches ln_post: running its out_proj / ln_2 / MLP on the F class rows must give what the
+    full-width last block gives (same per-token arithmetic; different GEMM tile paths may round the fp32 sums in another order)."""
+    c = next(x for x in mg.VIT_CASES if x["name"] == name)
+    for dtype in (torch.float16, torch.bfloat16):
+        m = _encoder(c, dtype)
+        u8 = mg.vit_pixels(c).cuda()
+        assert m.cls_only_last_block
+        y = m.encode_frames_u8(u8)
+        m.cls_only_last_block = False
+        y_full = m.encode_frames_u8(u8)
+        d = (y - y_full).abs().max().item()
+        print(f"{name} {dtype}: class-rows-only vs full last block: max abs diff {d:.2e}")
+        assert d <= (2e-4 if dtype == torch.float16 else 2e-3) * max(1.0, y_full.abs().max().item())
+
+
 def test_encoder_chunking_and_batch_independence():
     c = mg.VIT_CASES[0]
     m = _encoder(c, torch.bfloat16)

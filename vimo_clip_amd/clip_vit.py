@@ -93,6 +93,7 @@ class VisionTransformer(nn.Module):
         self.residual_dtype = residual_dtype
         self._w16 = {}          # name -> (param version, 16-bit copy)
         self.fuse_add_ln = True  # False: x += GEMM in the epilogue (fp32 read-modify-write), plain LayerNorm after it
+        self.cls_only_last_block = True  # last block's out_proj / MLP on the F class rows only (what ln_post reads)
         self.exact_patch_embed = True   # split-precision patch GEMM (fp32-accurate; +0.2 % FLOPs): see patch_operands()
         self.frame_chunk = 256  # frames per pass (bounds activation memory; F*N*4D*2 B for the MLP buffer)
         self._init_weights()
@@ -186,11 +187,33 @@ class VisionTransformer(nn.Module):
         h = None
         for i, blk in enumerate(blocks):
             pre = f"blk{i}."
+            last = i + 1 == len(blocks)
             if h is None:
                 h, *_ = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, dt16)
             qkv = ops.linear(h, self.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
             o, _ = ops.attention_vit(qkv, F, N, H)
             del qkv
+            if last and self.cls_only_last_block:
+                # Only x[:, 0] of the last block reaches ln_post (`x[:, 0, :]`, modeling_clip.py:650; OpenAI clip model.py
+                # `x = self.ln_post(x[:, 0, :])`): its out_proj, ln_2, MLP and residual adds are per-token maps, so they run on
+                # the F class rows instead of the F*N token rows -- the same arithmetic on 1/N of the rows (the attention itself
+                # still needs every token's K and V).  Saves two of the 96 large GEMMs and two add+LayerNorm passes per step.
+                o_cls = o.view(F, N, D)[:, 0, :]                      # strided rows (lda = N*D)
+                x_cls = x.view(F, N, D)[:, 0, :]
+                if fused:
+                    a = ops.linear(o_cls, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)
+                    hc = ops.add_layernorm_(x, a, blk.ln_2.weight, blk.ln_2.bias, rows=F, ldx=N * D, ldb=D)
+                    u = ops.linear(hc, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+                    m = ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias)
+                    cls = ops.add_layernorm_(x, m, self.ln_post.weight, self.ln_post.bias, rows=F, ldx=N * D, ldb=D, write_x=False)
+                else:
+                    ops.linear(o_cls, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x_cls, out=x_cls)
+                    hc, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16, rows=F, ldx=N * D)
+                    u = ops.linear(hc, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+                    ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=x_cls, out=x_cls)
+                    cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
+                del u, o
+                break
             if fused:
                 a = ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)
                 h = ops.add_layernorm_(x, a, blk.ln_2.weight, blk.ln_2.bias)
@@ -200,7 +223,6 @@ class VisionTransformer(nn.Module):
             if trace is not None:
                 trace.append((f"blk{i}.attn", x.float().clone()))
             u = ops.linear(h, self.w16(pre + "c_fc", blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
-            last = i + 1 == len(blocks)
             if fused:
                 m = ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias)
                 if last:       # only the class rows are needed after the last block: x[cls] + m[cls] -> ln_post
