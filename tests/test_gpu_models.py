@@ -500,3 +500,31 @@ def test_student_full_size_step_properties_vit_b32():
         rel = ((got - ref).norm() / (ref.norm() + 1e-20)).item()
         print(f"3-clip step grad {k}: rel L2 {rel:.2e}")
         assert rel <= 2e-2, (k, rel)          # measured 3.5e-3 .. 6.8e-3 (bf16 activations end to end)
+
+
+def test_student_last_block_on_class_rows_trains_the_same_function():
+    """Forward + backward with the last block's out_proj / MLP on the class rows only == the full-width last block (same loss,
+    same gradients up to fp32 summation order in the smaller wgrad GEMMs)."""
+    from vimo_clip_amd.losses import classification_loss, distillation_loss
+    name, B, T, seed = "ViT-tiny/32", 4, 6, 91
+    R, E = synth.VIT_GEOMETRY[name][0], synth.VIT_GEOMETRY[name][5]
+    vids = synth.randint_u8(seed, "vids", (B, T, 3, R, R)).cuda()
+    teacher = synth.normal(seed, "teacher", (B, T + 1, E)).cuda()
+    labels = synth.multi_hot_labels(seed, "labels", B, 140).cuda()
+    res = []
+    for cls_only in (True, False):
+        m, _ = _student(name, seed, torch.bfloat16)
+        m.train()
+        m.visual_encoder.cls_only_last_block = cls_only
+        emb, emb_d, logits = m(vids)
+        loss = distillation_loss(emb_d, teacher[:, :-1, :], mode="cosine") + classification_loss(logits, labels, positive_weight=9)
+        loss.backward()
+        res.append((loss.item(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]), (res[0][0], res[1][0])
+    worst = 0.0
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
+        worst = max(worst, rel)
+        assert rel <= 1e-3, (k, rel)
+    print(f"class-rows-only last block: loss {res[0][0]:.6f} vs {res[1][0]:.6f}, worst gradient rel L2 diff {worst:.2e}")

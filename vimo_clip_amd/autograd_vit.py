@@ -12,8 +12,11 @@ from . import autograd_ops as ag
 from . import ops
 
 
-def vit_tokens_train(model, x: torch.Tensor, wrap_quirk: bool = False):
-    """x: u8 [F,3,R,R] frames or float pixel values.  Returns the final residual stream [F*N, D]."""
+def vit_tokens_train(model, x: torch.Tensor, wrap_quirk: bool = False, cls_only: bool = True):
+    """x: u8 [F,3,R,R] frames or float pixel values.  Returns (the final residual stream, F, N, rows_are_cls).
+    cls_only: only x[:, 0] of the last block reaches ln_post, so its out_proj / ln_2 / MLP run on the F class rows (forward and,
+    through autograd, backward: the dgrad / wgrad GEMMs of those four linears shrink by N as well); the stream returned is then
+    [F, D].  The attention of the last block still sees every token (its K / V gradients flow to all rows)."""
     dt16, D, H = model.compute_dtype, model.width, model.heads
     F = x.shape[0]
     g = model.input_resolution // model.patch_size
@@ -29,17 +32,20 @@ def vit_tokens_train(model, x: torch.Tensor, wrap_quirk: bool = False):
     xs = ag.layernorm(xs, model.ln_pre.weight, model.ln_pre.bias, dt16, out_f32=(model.residual_dtype == torch.float32))
     if model.residual_dtype != torch.float32:
         xs = ag.cast(xs, model.residual_dtype)
-    for blk in model.transformer.resblocks:
+    blocks = list(model.transformer.resblocks)
+    for i, blk in enumerate(blocks):
         h, xs = ag.layernorm(xs, blk.ln_1.weight, blk.ln_1.bias, dt16, passthrough=True)
         qkv = ag.linear(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
         o = ag.SelfAttnPackedFn.apply(qkv, None, F, N, H)
+        if cls_only and i + 1 == len(blocks):
+            o, xs = _ClsRowsFn.apply(o, F, N), _ClsRowsFn.apply(xs, F, N)
         xs = ag.linear(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, res=xs,
                        out_f32=(model.residual_dtype == torch.float32))
         h, xs = ag.layernorm(xs, blk.ln_2.weight, blk.ln_2.bias, dt16, passthrough=True)
         u = ag.linear(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
         xs = ag.linear(u, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, res=xs,
                        out_f32=(model.residual_dtype == torch.float32))
-    return xs, F, N
+    return xs, F, N, cls_only
 
 
 class _ClsRowsFn(torch.autograd.Function):
@@ -99,7 +105,7 @@ class _ProjFn(torch.autograd.Function):
 
 def vit_forward_train(model, x: torch.Tensor, wrap_quirk: bool = False) -> torch.Tensor:
     """[F,3,R,R] -> [F,E] f32 embeddings, differentiable w.r.t. every ViT parameter."""
-    xs, F, N = vit_tokens_train(model, x, wrap_quirk)
-    cls = _ClsRowsFn.apply(xs, F, N)
+    xs, F, N, rows_are_cls = vit_tokens_train(model, x, wrap_quirk, cls_only=getattr(model, "cls_only_last_block", True))
+    cls = xs if rows_are_cls else _ClsRowsFn.apply(xs, F, N)
     h = ag.layernorm(cls, model.ln_post.weight, model.ln_post.bias, model.compute_dtype)
     return _ProjFn.apply(h, model.proj)
