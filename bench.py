@@ -328,7 +328,56 @@ def tfam_extras(dev, rank, world, cdt):
     out["adamw_roofline"] = {"bound": "hbm", "achieved": round(bytes_adam / t_adam / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(bytes_adam / t_adam / 8e12, 4), "params": arena.numel,
                              "note": "133 MB of state fits the 256 MiB Infinity Cache: MALL-resident, not an HBM-only figure"}
+    if world == 1:
+        try:
+            out["tfam_train_small_batch"] = tfam_small_batch_train(dev, cdt, m)
+        except Exception as e:      # noqa: BLE001
+            out["tfam_train_small_batch"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def tfam_small_batch_train(dev, cdt, m, batches=(8, 64), iters=50):
+    """The reference's own batch size (TFAM/train_and_eval.py:34 batch_size = 8 per GPU) is launch-bound: ~230 launches per step.
+    Eager step vs ONE hipGraph replay per step (graphs.GraphedTrainStep: step count, lr, bias corrections and dropout seeds in
+    device memory, advanced by vmc_train_tick inside the graph).  Single process; wall clock around synchronised loops."""
+    from vimo_clip_amd import synth
+    from vimo_clip_amd.graphs import GraphedTrainStep
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    m.train()
+    opt = FusedAdam(GradArena(m.used_parameters()), lr=1e-4, weight_decay=0.1, decoupled=True)
+    res = {}
+    data = {}
+    for B in batches:
+        data[B] = (synth.normal(30, f"rgb{B}", (B, 16, 768)).to(dev), synth.normal(30, f"mot{B}", (B, 16, 768)).to(dev),
+                   torch.ones(B, 16, dtype=torch.bool, device=dev), synth.multi_hot_labels(30, f"lab{B}", B, 140).to(dev))
+
+    def eager_step(rgb, mot, mk, y):
+        loss = bce_with_logits_loss(m(rgb, mot, mask_rgb=mk, mask_flow=mk), y)
+        loss.backward()
+        opt.step()
+
+    for B in batches:
+        res[f"B{B}_eager_ms"] = round(1e3 * _time_cuda(lambda: eager_step(*data[B]), iters), 4)
+    opt.enable_device_state(base_seed=0)
+    m.use_device_seeds(opt)
+
+    def dev_step(rgb, mot, mk, y):
+        opt.tick()
+        out = m(rgb, mot, mask_rgb=mk, mask_flow=mk)
+        loss = bce_with_logits_loss(out, y)
+        loss.backward()
+        opt.step()
+        return loss.detach(), out.detach()
+
+    g = GraphedTrainStep(dev_step, opt)
+    for B in batches:
+        rgb, mot, mk, y = data[B]
+        t = _time_cuda(lambda: g(rgb, mot, mk, mk, y), iters)
+        res[f"B{B}_captured_ms"] = round(1e3 * t, 4)
+        res[f"B{B}_captured_clips_per_s"] = round(B / t, 1)
+    m.use_device_seeds(None)
+    return res
 
 
 def selftest_spawn(rank: int, world: int) -> None:
@@ -396,6 +445,7 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     if args.only == "tfam":
         print(json.dumps(tfam_forward_block(dev, rank, cdt)), flush=True)
+        print(json.dumps(tfam_extras(dev, rank, world, cdt)), flush=True)
         return
     model = VisionTransformer.from_name(args.model, compute_dtype=cdt).to(dev).eval()
     sd = synth.vit_state_dict(args.model, seed=2)

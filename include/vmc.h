@@ -346,6 +346,17 @@ int vmc_tfam_forward(const float* x, const float* motion, const uint8_t* mask, c
  */
 int vmc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int decoupled_wd, int step, float grad_scale, void* stream);
+/* Device-resident step state for hipGraph-captured training steps (the step count, the bias corrections, the learning rate and
+ * the dropout seeds must not be host scalars frozen into the graph -- ADVICE r1).
+ *   state  u64 [2 + n_seeds] in device memory: [0] step count t (start at 0), [1] base seed, [2..] this step's dropout seeds
+ *   hyper  f32 [4], 16-byte aligned: {lr, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), grad_scale}; the host writes [0] and [3]
+ * vmc_train_tick: t += 1, recomputes hyper[1..2] and the n_seeds seeds (splitmix of base seed, t and the index); enqueue it once
+ * per step before the forward.  vmc_adam_step_dev = vmc_adam_step reading its four scalars from `hyper`.
+ * SEED ARGUMENTS (vmc_dropout, vmc_postnorm_dropout_fwd, vmc_attention_fwd / _bwd): a value < 2^63 is the seed itself; with bit
+ * 63 set the low 63 bits are the ADDRESS of a u64 in device memory holding it (e.g. &state[2 + i]), read at kernel start. */
+int vmc_train_tick(void* state, float* hyper, float beta1, float beta2, int n_seeds, void* stream);
+int vmc_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
+                      float eps, float weight_decay, int decoupled_wd, void* stream);
 /* sum of squares of a flat f32 buffer, accumulated (+=) into out[0] (global grad norm). */
 int vmc_sumsq(const float* x, size_t n, float* out, void* stream);
 

@@ -296,3 +296,38 @@ def test_backward_overlapped_allreduce_two_ranks_one_gpu():
     assert res[0][4] == res[1][4]                            # replicas stay identical
     early, nb = res[0][2], res[0][3]
     assert early[0] == 0 and early[1] >= nb - 1 and early[2] >= nb - 1, (early, nb)
+
+
+def test_trainer_with_captured_steps_follows_the_uncaptured_trainer():
+    """ModelTrainer(use_graphs=True): every training step is one hipGraph replay per batch shape (graphs.GraphedTrainStep; step
+    count, cosine-schedule lr, bias corrections in device memory).  Two epochs over ragged clips (several shapes, lr changes
+    between the epochs) must give the epoch losses / mAP and the final weights of the uncaptured trainer."""
+    from vimo_clip_amd.TFAM.data.dataset import SyntheticEmbeddingDataset
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    from vimo_clip_amd.TFAM.train_and_eval import Config, ModelTrainer
+    D, H, L, FF, C, BS = 256, 8, 2, 512, 140, 8
+    ytr, yva = _labels("train", 96), _labels("val", 32)
+    tr = SyntheticEmbeddingDataset(ytr, D, tmin=12, tmax=16, seed=5, signal=0.6)
+    va = SyntheticEmbeddingDataset(yva, D, tmin=12, tmax=16, seed=6, signal=0.6)
+    runs = []
+    for graphs in (False, True):
+        cfg = Config(epochs=2, batch_size=BS, d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, dropout=0.0, mlp_dropout=0.0,
+                     device="cuda", checkpoint_dir=None, use_graphs=graphs)
+        model = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda()
+        model.load_state_dict(synth.tfam_state_dict(D, H, L, FF, C, 77), strict=True)
+        t = ModelTrainer(model, tr, va, cfg)
+        stats = []
+        for ep in range(2):
+            stats.append(t.train_epoch(ep) + t.validate(ep))
+            t.scheduler.step()
+        runs.append((stats, {k: v.detach().clone() for k, v in model.state_dict().items()}, t))
+    (se, we, te), (sg, wg, tg) = runs
+    print("eager   ", se)
+    print("captured", sg)
+    assert tg._graphed_train is not None and 1 <= len(tg._graphed_train._graphs) <= 16 and te._graphed_train is None
+    assert tg.optimizer.step_count == te.optimizer.step_count == 24 == int(tg.optimizer.dev_state[0].item())
+    for a, b in zip(se, sg):
+        assert all(abs(x - y) <= 2e-3 * max(abs(x), 1e-3) for x, y in zip(a, b)), (a, b)
+    for k in we:
+        d = (we[k].float() - wg[k].float()).abs().max().item()
+        assert d <= 5e-3 * max(1e-3, we[k].float().abs().max().item()), (k, d)

@@ -528,3 +528,72 @@ def test_student_last_block_on_class_rows_trains_the_same_function():
         worst = max(worst, rel)
         assert rel <= 1e-3, (k, rel)
     print(f"class-rows-only last block: loss {res[0][0]:.6f} vs {res[1][0]:.6f}, worst gradient rel L2 diff {worst:.2e}")
+
+
+def test_device_state_adam_and_tick_match_host_adam():
+    """vmc_train_tick + vmc_adam_step_dev (step count, bias corrections, lr from device memory) == vmc_adam_step over 5 steps."""
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    mk = lambda: [torch.nn.Parameter(synth.normal(8, f"p{i}", sh).cuda()) for i, sh in enumerate([(64, 32), (33,), (8, 8)])]
+    pa, pb = mk(), mk()
+    oa = FusedAdam(GradArena(pa), lr=3e-3, weight_decay=0.1, decoupled=True)
+    ob = FusedAdam(GradArena(pb), lr=3e-3, weight_decay=0.1, decoupled=True).enable_device_state(base_seed=7)
+    for step in range(5):
+        if step == 3:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 1e-3
+            ob.sync_hyper()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = synth.normal(9 + step, f"g{i}", tuple(a.shape)).cuda()
+            a._vmc_grad.copy_(g)
+            b._vmc_grad.copy_(g)
+        oa.step()
+        ob.tick()
+        ob.step()
+    assert int(ob.dev_state[0].item()) == 5 == ob.step_count
+    for a, b in zip(pa, pb):
+        assert (a.detach() - b.detach()).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
+    seeds = ob.dev_state[2:10].tolist()
+    assert len(set(seeds)) == 8 and all(0 <= s_ < (1 << 63) for s_ in seeds)
+    ob.tick()
+    assert ob.dev_state[2:10].tolist() != seeds                # every step draws new dropout seeds
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_captured_train_steps_equal_eager_device_state_steps(p_drop):
+    """hipGraph-captured TFAM training steps (tick + fwd + bwd + AdamW): five replays follow the same trajectory as five eager
+    steps in the same device-state mode -- also with dropout, whose masks must change from step to step inside ONE graph."""
+    from vimo_clip_amd.graphs import GraphedTrainStep
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    c = mg.TFAM_CASES[0]
+    rgb, mot, mr, mf = (t.cuda() for t in mg.tfam_inputs(c))
+    y = synth.multi_hot_labels(c["seed"], "labels", c["B"], c["C"]).cuda()
+    traj = []
+    for captured in (False, True):
+        m = AMO_CLIP(d_model=c["D"], nhead=c["H"], num_layers=c["L"], dim_feedforward=c["ff"], num_classes=c["C"], dropout=p_drop,
+                     mlp_dropout=p_drop, device="cuda", **mg.tfam_mode_kwargs(c["mode"])).cuda().train()
+        m.load_state_dict(synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"]), strict=True)
+        opt = FusedAdam(GradArena(m.used_parameters()), lr=1e-3, weight_decay=0.1, decoupled=True).enable_device_state(base_seed=11)
+        m.use_device_seeds(opt)
+
+        def step(a, b, cm, d, yy):
+            opt.tick()
+            out = m(a, b, mask_rgb=cm, mask_flow=d)
+            loss = bce_with_logits_loss(out, yy)
+            loss.backward()
+            opt.step()
+            return loss.detach(), out.detach()
+
+        run = GraphedTrainStep(step, opt) if captured else step
+        losses = [float(run(rgb, mot, mr, mf, y)[0].clone()) for _ in range(5)]
+        traj.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}, opt.step_count, int(opt.dev_state[0].item())))
+    (le, pe, ce, de), (lc, pc, cc, dc) = traj
+    print(f"dropout {p_drop}: eager {le}  captured {lc}")
+    assert ce == de == cc == dc == 5                          # the capture's warm-up did not count as a step
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(le, lc)), (le, lc)
+    assert le[-1] < le[0]
+    if p_drop > 0:
+        assert len({round(x, 6) for x in lc}) == 5            # masks differ from replay to replay
+    for k in pe:
+        d = (pe[k] - pc[k]).abs().max().item()
+        assert d <= 5e-3 * max(1e-3, pe[k].abs().max().item()), (k, d)

@@ -203,8 +203,17 @@ class AMO_CLIP(nn.Module):
         self._seed_base = int(seed)
         self._seed_iter = itertools.count(1)
 
+    def use_device_seeds(self, optimizer):
+        """Draw dropout seeds from ``optimizer``'s device-resident step state (FusedAdam.enable_device_state): every call site
+        of a step gets the ADDRESS of its seed, which vmc_train_tick rewrites before each step -- what a captured step needs."""
+        self._seed_source = optimizer
+
     def _next_seed(self):
-        return ((self._seed_base << 24) ^ next(self._seed_iter)) & 0xFFFFFFFFFFFFFFFF
+        src = getattr(self, "_seed_source", None)
+        if src is not None and self.training:
+            i = self._seed_site = getattr(self, "_seed_site", -1) + 1
+            return src.seed_address(i)
+        return ((self._seed_base << 24) ^ next(self._seed_iter)) & 0x7FFFFFFFFFFFFFFF      # bit 63 is the pointer tag (include/vmc.h)
 
     def positional_encoding(self, seq_len):
         """Sinusoidal table [seq_len, d_model] (:88-97), produced by the same kernel that adds it."""
@@ -273,6 +282,7 @@ class AMO_CLIP(nn.Module):
         B = rgb_emb.shape[0]
         m_rgb, m_flow = _mask_u8(mask_rgb, dev), _mask_u8(mask_flow, dev)
         seed_fn = self._next_seed
+        self._seed_site = -1                              # device-seed mode: call sites are numbered from 0 in every forward
         if self.fused_inference and not self.training and not torch.is_grad_enabled():
             out = self._forward_fused(rgb_emb, motion_emb, m_rgb, m_flow)
             if out is not None:

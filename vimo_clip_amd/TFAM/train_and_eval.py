@@ -199,9 +199,25 @@ class ModelTrainer:
         self.scheduler = CosineAnnealingLR(self.optimizer, T_max=config.epochs, eta_min=1e-6)
         self.reducer = parallel.GradientAllReducer(self.arena.flat_grad).attach(self.arena)   # buckets go out during the backward
         self._graphed_eval = GraphedEvalForward(model, config) if getattr(config, "use_graphs", False) else None
+        self._graphed_train = None
+        if getattr(config, "use_graphs", False) and world == 1:
+            # captured training steps: step count / lr / dropout seeds in device memory (optim.FusedAdam.enable_device_state)
+            from ..graphs import GraphedTrainStep
+            self.optimizer.enable_device_state(base_seed=config.seed)
+            model.use_device_seeds(self.optimizer)
+            self._graphed_train = GraphedTrainStep(self._device_state_step, self.optimizer)
 
     def _forward(self, batch):
         return _model_forward(self.model, batch, self.config), batch["labels"].to(self.config.device)
+
+    def _device_state_step(self, rgb, mot, mr, mf, labels):
+        """tick + forward + loss + backward + AdamW with every step-dependent scalar read from device memory."""
+        self.optimizer.tick()
+        output = self.model(rgb, mot, mask_rgb=mr, mask_flow=mf)
+        loss = self.criterion(output, labels)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach(), output.detach()
 
     def train_epoch(self, epoch):
         self.model.train()
@@ -209,11 +225,20 @@ class ModelTrainer:
         total, n = torch.zeros((), device=self.config.device), 0
         g = torch.Generator().manual_seed(self.config.seed + epoch)
         order = torch.randperm(len(self.train_set), generator=g).tolist()
+        if self._graphed_train is not None:
+            self.optimizer.sync_hyper()                     # the epoch's learning rate -> device memory
         for batch in batches(self.train_set, self.config.batch_size, self.rank, self.world, order=order, motion_key=self.config.motion_key):
-            output, labels = self._forward(batch)
-            loss = self.criterion(output, labels)
-            loss.backward()
-            self.optimizer.step(grad_scale=self.reducer.all_reduce())
+            if self._graphed_train is not None:
+                dev, mk = self.config.device, self.config.motion_key
+                labels = batch["labels"].to(dev)
+                loss, output = self._graphed_train(batch["embeddings"].to(dev), batch[f"{mk}_embeddings"].to(dev),
+                                                   batch["mask_rgb"].to(dev), batch[f"mask_{mk}"].to(dev), labels)
+                loss, output = loss.clone(), output.clone()
+            else:
+                output, labels = self._forward(batch)
+                loss = self.criterion(output, labels)
+                loss.backward()
+                self.optimizer.step(grad_scale=self.reducer.all_reduce())
             total += loss.detach()
             n += 1
             self.mAP_metric.update(output, labels.to(dtype=torch.int))

@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(64) attn_generic_fwd(const uint16_t* __restric
                                                        const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
                                                        uint16_t* __restrict__ op, float* __restrict__ lse, int H, int Tq,
                                                        int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
-                                                       float drop_p, unsigned long long seed) {
+                                                       float drop_p, unsigned long long seed_arg) {
+  const unsigned long long seed = drop_p > 0.f ? resolve_seed(seed_arg) : 0;
   __shared__ float qs[ATT_MAX_DH];
   __shared__ float ps[ATT_MAX_TK];
   const int lane = threadIdx.x;
@@ -423,7 +424,8 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_q(const uint16_t* __restr
                                                          const float* __restrict__ lse, uint16_t* __restrict__ dqp,
                                                          float* __restrict__ delta, int H, int Tq, int Tk, int dh, int ldq,
                                                          int ldk, int ldv, int ldo, int lddq, float scale, float drop_p,
-                                                         unsigned long long seed) {
+                                                         unsigned long long seed_arg) {
+  const unsigned long long seed = drop_p > 0.f ? resolve_seed(seed_arg) : 0;
   __shared__ float qs[ATT_MAX_DH];
   __shared__ float dos[ATT_MAX_DH];
   __shared__ float ds[ATT_MAX_TK];
@@ -468,7 +470,8 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __rest
                                                           const float* __restrict__ delta, uint16_t* __restrict__ dkp,
                                                           uint16_t* __restrict__ dvp, int H, int Tq, int Tk, int dh, int ldq,
                                                           int ldk, int ldv, int ldo, int lddk, int lddv, float scale,
-                                                          float drop_p, unsigned long long seed) {
+                                                          float drop_p, unsigned long long seed_arg) {
+  const unsigned long long seed = drop_p > 0.f ? resolve_seed(seed_arg) : 0;
   __shared__ float ks[ATT_MAX_DH];
   __shared__ float vs[ATT_MAX_DH];
   __shared__ float pbuf[ATT_MAX_TK];   // p[t]  for this key

@@ -116,6 +116,13 @@ __device__ inline uint32_t hash32(uint64_t seed, uint64_t i) {
   x ^= x >> 31;
   return (uint32_t)(x >> 32);
 }
+// Seed arguments of the ABI: a plain 63-bit value, or -- bit 63 set -- the address (low 63 bits) of a uint64 in device memory
+// that holds the seed.  A hipGraph-captured training step passes addresses: the captured launches re-read the seeds that
+// vmc_train_tick rewrites before every replay (host scalars would be frozen into the graph).
+#define VMC_SEED_IS_PTR (1ull << 63)
+__device__ inline uint64_t resolve_seed(uint64_t s) {
+  return (s & VMC_SEED_IS_PTR) ? *(const uint64_t*)(uintptr_t)(s & ~VMC_SEED_IS_PTR) : s;
+}
 __device__ inline float dropout_factor(float p, uint64_t seed, uint64_t i) {
   if (p <= 0.f) return 1.0f;
   return hash32(seed, i) >= (uint32_t)((double)p * 4294967296.0) ? 1.0f / (1.0f - p) : 0.0f;

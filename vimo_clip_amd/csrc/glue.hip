@@ -68,7 +68,8 @@ extern "C" int vmc_assemble_tokens(const void* xp, const float* cls, const float
 // Inverted dropout with a counter-based keep mask: keep(i) = hash(seed, i) >= p; y = x * keep / (1 - p).
 // The backward calls the same function on dy with the same (seed, p): no mask is stored.
 template <typename T>
-__global__ void dropout_kernel(const void* __restrict__ x, void* __restrict__ y, size_t n, float p, uint64_t seed, int f32) {
+__global__ void dropout_kernel(const void* __restrict__ x, void* __restrict__ y, size_t n, float p, uint64_t seed_arg, int f32) {
+  const uint64_t seed = resolve_seed(seed_arg);
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
   const float sc = 1.0f / (1.0f - p);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(256) postnorm_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ sum_out, float* __restrict__ y32, uint16_t* __restrict__ y16,
                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, float eps,
-                                                       float p1, uint64_t seed1, float p2, uint64_t seed2) {
+                                                       float p1, uint64_t seed1_arg, float p2, uint64_t seed2_arg) {
+  const uint64_t seed1 = p1 > 0.f ? resolve_seed(seed1_arg) : 0, seed2 = p2 > 0.f ? resolve_seed(seed2_arg) : 0;
   // p1 / p2 > 0: the branch goes through one or two dropouts first (nn.Dropout after the FFN's second Linear and the
   // block's own dropout, AMO_CLIP.py:28,50) -- same counter-based masks as vmc_dropout on the flat element index
   constexpr int D = CH * 256;

@@ -171,7 +171,11 @@ extern "C" int vmc_cross_entropy_loss(const float* logits, const long long* targ
 // 16 B read (p, g, m, v) + 12 B write per parameter; float4 vectorised, grid-stride.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, int decoupled, float step_size, float inv_sqrt_bc2, float gscale) {
+                                                   float wd, int decoupled, float step_size, float inv_sqrt_bc2, float gscale,
+                                                   const float* __restrict__ hyper) {
+  if (hyper != nullptr) {      // captured training step: {lr, lr / (1 - b1^t), 1 / sqrt(1 - b2^t), grad_scale} live in device memory
+    lr = hyper[0]; step_size = hyper[1]; inv_sqrt_bc2 = hyper[2]; gscale = hyper[3];
+  }
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 pp = ((float4*)p)[i];
@@ -208,7 +212,48 @@ extern "C" int vmc_adam_step(float* p, const float* g, float* m, float* v, size_
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, decoupled_wd, step_size, inv_sqrt_bc2, grad_scale);
+                     beta2, eps, weight_decay, decoupled_wd, step_size, inv_sqrt_bc2, grad_scale, (const float*)nullptr);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- device-resident step state (hipGraph-captured training steps) ------------------------------------------------------
+// state[0] = step count t, state[1] = base seed, state[2 .. 2 + n_seeds) = the dropout seeds of this step (one per call site);
+// hyper = {lr (host-written), lr / (1 - b1^t), 1 / sqrt(1 - b2^t), grad_scale (host-written)}.
+__global__ void train_tick_kernel(unsigned long long* __restrict__ state, float* __restrict__ hyper, float b1, float b2, int n_seeds) {
+  __shared__ unsigned long long t_sh;
+  if (threadIdx.x == 0) {
+    const unsigned long long t = state[0] + 1;
+    state[0] = t;
+    t_sh = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    hyper[1] = (float)((double)hyper[0] / bc1);
+    hyper[2] = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  const unsigned long long t = t_sh, base = state[1];
+  for (int i = threadIdx.x; i < n_seeds; i += blockDim.x) {
+    unsigned long long x = base ^ (t * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xD1B54A32D192ED03ull);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    state[2 + i] = x & ~VMC_SEED_IS_PTR;        // a seed VALUE never carries the pointer tag
+  }
+}
+
+extern "C" int vmc_train_tick(void* state, float* hyper, float beta1, float beta2, int n_seeds, void* stream) {
+  if (!state || !hyper || n_seeds < 0) return VMC_E_ARG;
+  hipLaunchKernelGGL(train_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)state, hyper, beta1, beta2, n_seeds);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vmc_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
+                                 float eps, float weight_decay, int decoupled_wd, void* stream) {
+  if (!p || !g || !m || !v || !hyper || n == 0) return VMC_E_ARG;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)hyper) & 15) return VMC_E_ALIGN;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+                     beta2, eps, weight_decay, decoupled_wd, 0.f, 0.f, 0.f, hyper);
   VMC_CHECK_LAUNCH();
   return 0;
 }

@@ -37,3 +37,41 @@ class GraphedCallable:
     def replay(self):
         self.graph.replay()
         return self.static_outputs
+
+
+class GraphedTrainStep:
+    """One training step (vmc_train_tick + forward + backward + fused Adam) per batch shape as a hipGraph replay.
+
+    The optimiser must be in device-state mode (``FusedAdam.enable_device_state``): the step count, the bias corrections, the
+    learning rate and the dropout seeds then live in device memory, so every captured launch has constant arguments and a
+    replay IS the next step (host scalars would be frozen into the graph).  The warm-up run that precedes a
+    capture is undone (parameters, Adam moments and the step state are restored), so capturing a new batch shape does not
+    train on its example batch.  Single process only: the bucketed gradient all-reduce is not captured."""
+
+    def __init__(self, step_fn, optimizer, max_graphs: int = 16):
+        if getattr(optimizer, "dev_state", None) is None:
+            raise ValueError("GraphedTrainStep needs FusedAdam.enable_device_state()")
+        self.step_fn, self.opt, self.max_graphs = step_fn, optimizer, max_graphs
+        self._graphs = {}
+
+    def _capture(self, inputs):
+        o, a = self.opt, self.opt.arena
+        live = (a.flat_param, a.flat_grad, o.m, o.v, o.dev_state, o.dev_hyper)
+        saved = [t.clone() for t in live]
+        count = o.step_count
+        g = GraphedCallable(self.step_fn, *inputs, warmup=1)
+        for t, s in zip(live, saved):
+            t.copy_(s)
+        o.step_count = count
+        return g
+
+    def __call__(self, *inputs):
+        key = tuple((tuple(x.shape), x.dtype) if torch.is_tensor(x) else x for x in inputs)
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= self.max_graphs:
+                return self.step_fn(*inputs)                   # too many shapes: eager step (same device-state arithmetic)
+            g = self._graphs[key] = self._capture(inputs)
+        out = g(*inputs)
+        self.opt.step_count += 1                               # host mirror of the device step count
+        return out

@@ -81,8 +81,51 @@ class FusedAdam:
     def zero_grad(self, set_to_none: bool = False):
         pass                                       # gradients are overwritten in place every backward
 
+    # ---- device-resident step state: what a hipGraph-captured training step needs ----------------------------
+    N_SEEDS = 256                                  # dropout call sites per step a model may draw
+
+    def enable_device_state(self, base_seed: int = 0x5EED):
+        """Move the step count / bias corrections / learning rate / dropout seeds into device memory (vmc_train_tick,
+        vmc_adam_step_dev): ``tick()`` + ``step()`` then enqueue only launches whose arguments never change, so a captured
+        step replays correctly.  ``sync_hyper()`` must be called (outside a capture) whenever lr or grad_scale change."""
+        dev = self.arena.flat_param.device
+        self.dev_state = torch.zeros(2 + self.N_SEEDS, dtype=torch.int64, device=dev)
+        self.dev_state[0] = self.step_count
+        self.dev_state[1] = int(base_seed) & 0x7FFFFFFFFFFFFFFF
+        self.dev_hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = None
+        self.sync_hyper()
+        return self
+
+    def sync_hyper(self, grad_scale: float = 1.0):
+        want = (float(self.param_groups[0]["lr"]), float(grad_scale))
+        if self._hyper_host != want:
+            self.dev_hyper[0] = want[0]
+            self.dev_hyper[3] = want[1]
+            self._hyper_host = want
+
+    def tick(self):
+        """Start of a step in device-state mode: t += 1, bias corrections and this step's dropout seeds (one launch)."""
+        check(lib.vmc_train_tick(ptr(self.dev_state), ptr(self.dev_hyper), float(self.betas[0]), float(self.betas[1]), self.N_SEEDS,
+                                 stream()), "train_tick")
+        self.step_count += 1
+
+    def seed_address(self, i: int) -> int:
+        """Seed argument (pointer form, include/vmc.h) of dropout call site i of the current step."""
+        if not 0 <= i < self.N_SEEDS:
+            raise IndexError("more dropout call sites per step than FusedAdam.N_SEEDS")
+        return (1 << 63) | (self.dev_state.data_ptr() + 8 * (2 + i))
+
     def step(self, grad_scale: float = 1.0, max_grad_norm=None):
         a = self.arena
+        if getattr(self, "dev_state", None) is not None:      # device-state mode: tick() already advanced t
+            if max_grad_norm is not None:
+                raise ValueError("gradient clipping needs a host read of the norm: not available in device-state mode")
+            check(lib.vmc_adam_step_dev(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, ptr(self.dev_hyper),
+                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                        int(self.decoupled), stream()), "adam_step_dev")
+            invalidate_weight_copies()
+            return
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
             grad_scale = clipped_grad_scale(float(a.grad_norm().item()), grad_scale, max_grad_norm)
         self.step_count += 1
