@@ -373,7 +373,7 @@ def tfam_small_batch_train(dev, cdt, m, batches=(8, 64), iters=50):
     g = GraphedTrainStep(dev_step, opt)
     for B in batches:
         rgb, mot, mk, y = data[B]
-        t = _time_cuda(lambda: g(rgb, mot, mk, mk, y), iters)
+        t = _time_cuda(lambda: g(rgb, mot, mk, y), iters)
         res[f"B{B}_captured_ms"] = round(1e3 * t, 4)
         res[f"B{B}_captured_clips_per_s"] = round(B / t, 1)
     m.use_device_seeds(None)

@@ -129,10 +129,13 @@ int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbi
                              void* workspace, size_t workspace_bytes, int dtype16, void* stream);
 
 /* vmc_linear with the large-problem kernel chosen PER CALL (A/B measurements in one process; the library keeps no
- * state): VMC_GEMM_TWOSTAGE = two-stage tiles only, VMC_GEMM_DEFAULT = what vmc_linear does (8-phase 256x256 kernel,
- * one tile per workgroup, the tile rows of a small last partial round handed to the small-tile kernel in a second
- * launch), VMC_GEMM_NO_TAIL_SPLIT = the same without that split.  Results are identical bit for bit across them. */
-enum { VMC_GEMM_TWOSTAGE = 0, VMC_GEMM_DEFAULT = 1, VMC_GEMM_NO_TAIL_SPLIT = 2, VMC_GEMM_VARIANTS = 3 };
+ * state): VMC_GEMM_TWOSTAGE = two-stage tiles only, VMC_GEMM_DEFAULT = what vmc_linear does (8-phase 256x256 kernel; the
+ * tile rows of a small last partial round handed to the small-tile kernel in a second launch; whole-tile problems with a
+ * bias and a 16-bit output walk their tiles in a persistent workgroup per CU that prefetches the next tile's operands),
+ * VMC_GEMM_NO_TAIL_SPLIT = the same without that split, VMC_GEMM_PERSISTENT = the persistent walk for every eligible
+ * epilogue, VMC_GEMM_ONE_TILE = never persistent (one tile per workgroup).  Results are identical bit for bit across them. */
+enum { VMC_GEMM_TWOSTAGE = 0, VMC_GEMM_DEFAULT = 1, VMC_GEMM_NO_TAIL_SPLIT = 2, VMC_GEMM_PERSISTENT = 3, VMC_GEMM_ONE_TILE = 4,
+       VMC_GEMM_VARIANTS = 5 };
 int vmc_linear_variant(const void* A, const void* W, const float* bias, const void* res, void* C,
                        int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                        int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,

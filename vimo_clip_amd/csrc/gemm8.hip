@@ -127,6 +127,110 @@ __device__ __forceinline__ void g8_nt_store(const uint4& o, uint16_t* dst) {
   __builtin_nontemporal_store((g8_u32x4){o.x, o.y, o.z, o.w}, (g8_u32x4*)dst);
 }
 
+// ---- fast epilogues of an interior 256x256 tile (shared by the one-tile and the persistent kernel) ----
+// 16-bit rows without residual / row remap (qkv, c_fc, dgrad): branch-free, the bias of this lane's 2 x 8 columns loaded once
+// instead of once per row (the generic path cannot hoist it past the stores).  16 stores per wave (32 with a pre-activation
+// side output).  Output stores are non-temporal: the tensor (400 .. 540 MB per ViT-L/14 launch) is larger than the Infinity
+// Cache and is read next by another kernel; +1.2 .. 1.5 % on the qkv / c_fc shapes.  Staging the tile through LDS for whole-row
+// stores was measured too and does not pay (profiles/README.md, round 2).
+template <typename T, int ACT>
+__device__ __forceinline__ void g8p_epilogue_store16(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], const float (&bv)[2][8], int m0,
+                                                    int n0, int wm, int wn, int r, int q) {
+  char* const ctile = g.C + ((size_t)m0 * g.ldc + n0) * 2;
+  uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 2u;
+  asm volatile("" : "+v"(clane));   // the 16 row offsets are formed here, not hoisted above the K loop
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        float v[8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mh][nh][mt][nt][j] + bv[nh][4 * nt + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
+        g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
+                    (uint16_t*)(ctile + (clane + (uint32_t)(128 * mh + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * nh)));
+      }
+}
+
+// Accumulate into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of four tile rows are
+// fetched together (8 x 32 B per lane in flight), then added and stored; no per-row branches.  32 stores per wave.
+template <typename T, int ACT>
+__device__ __forceinline__ void g8p_epilogue_res32(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], const float (&bv)[2][8], int m0,
+                                                  int n0, int wm, int wn, int r, int q) {
+  const char* const rtile = g.res + ((size_t)m0 * g.ldres + n0) * 4;
+  char* const ctile = g.C + ((size_t)m0 * g.ldc + n0) * 4;
+  uint32_t rlane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldres + 32 * wn + 8 * q) * 4u;
+  uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 4u;
+  asm volatile("" : "+v"(rlane), "+v"(clane));   // the row offsets are formed here, not hoisted above the K loop
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {             // two tile rows per batch: 8 x 32 B per lane in flight, 32 registers
+      float4 rr[2][2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const float* src = (const float*)(rtile + (rlane + (uint32_t)(128 * mh + 16 * (2 * mp + mi)) * (uint32_t)g.ldres * 4u + 512u * nh));
+          rr[mi][nh][0] = *(const float4*)src;
+          rr[mi][nh][1] = *(const float4*)(src + 4);
+        }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const int mt = 2 * mp + mi;
+          float* dst = (float*)(ctile + (clane + (uint32_t)(128 * mh + 16 * mt) * (uint32_t)g.ldc * 4u + 512u * nh));
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float4 x = rr[mi][nh][nt];
+            float4 o;
+            o.x = x.x + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][0] + bv[nh][4 * nt + 0]);
+            o.y = x.y + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][1] + bv[nh][4 * nt + 1]);
+            o.z = x.z + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][2] + bv[nh][4 * nt + 2]);
+            o.w = x.w + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][3] + bv[nh][4 * nt + 3]);
+            *(float4*)(dst + 4 * nt) = o;
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Which fast epilogue the whole problem qualifies for (tile interior checked by the caller).
+#define G8_EPI_GENERIC 0
+#define G8_EPI_STORE16 1
+#define G8_EPI_RES32 2
+VMC_HD int g8_epi_kind(const GemmArgs& g) {
+  const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.res == nullptr || (g.ldres & 7) == 0);
+  if (!vec8 || g.out_row_group) return G8_EPI_GENERIC;
+  if (!g.out_f32 && !g.res && (!g.zout || (g.ldz & 7) == 0)) return G8_EPI_STORE16;
+  if (g.out_f32 && g.res && g.res_f32 && !g.zout && !g.res_row_mod) return G8_EPI_RES32;
+  return G8_EPI_GENERIC;
+}
+
+// Tile order: ids run over column GROUPS of 4 tiles, rows inside a group.  The 32 tiles an XCD runs at once are then 8 row
+// panels x 4 column panels: the 4 W panels (2 MB at K = 1024) stay resident in that XCD's 4 MB L2 for the whole sweep and
+// only A panels stream.  Widths 2 / 8 / 16 measured within 0.5 % (2-3 % slower on qkv): profiles/README.md round 2.
+__device__ __forceinline__ void g8_tile_coords(const GemmArgs& g, int tile, int& tm, int& tn) {
+  constexpr int GC = 4;
+  const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
+  const int cg = tile / gsz;
+  if (cg < nfull) {
+    const int rem = tile - cg * gsz;
+    tm = rem / GC;
+    tn = cg * GC + rem % GC;
+  } else {
+    const int w = g.tiles_n - nfull * GC, rem = tile - nfull * gsz;
+    tm = rem / w;
+    tn = nfull * GC + rem % w;
+  }
+}
+
 template <typename T, int ACT>
 __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,25 +240,8 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, q = lane >> 4;
 
-  // Tile order: each XCD walks a contiguous id range (xcd_remap); ids run over column GROUPS of 4 tiles, rows
-  // inside a group.  The 32 tiles an XCD runs at once are then 8 row panels x 4 column panels: the 4 W panels
-  // (2 MB at K = 1024) stay resident in that XCD's 4 MB L2 for the whole sweep and only A panels stream.
-  const int tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  int tm, tn;
-  {
-    constexpr int GC = 4;      // widths 2 / 8 / 16 measured within 0.5 % (2-3 % slower on qkv): profiles/README.md round 2
-    const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
-    const int cg = tile / gsz;
-    if (cg < nfull) {
-      const int rem = tile - cg * gsz;
-      tm = rem / GC;
-      tn = cg * GC + rem % GC;
-    } else {
-      const int w = g.tiles_n - nfull * GC, rem = tile - nfull * gsz;
-      tm = rem / w;
-      tn = nfull * GC + rem % w;
-    }
-  }
+  int tm, tn;   // each XCD walks a contiguous id range (xcd_remap)
+  g8_tile_coords(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
 
   const char *sA0[2], *sA1[2], *sB0[2], *sB1[2];
@@ -210,8 +297,6 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
   if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
 
   const bool vec8 = gemm_vec8_ok(g);
-  // Interior tile writing 16-bit rows without residual / row remap (qkv, c_fc, dgrad): branch-free epilogue, the bias of
-  // this lane's 2 x 8 columns loaded once instead of once per row (the generic path below cannot hoist it past the stores).
   if (vec8 && !g.out_f32 && !g.res && !g.out_row_group && (!g.zout || (g.ldz & 7) == 0) && m0 + 256 <= g.M && n0 + 256 <= g.N) {
     float bv[2][8];
 #pragma unroll
@@ -319,6 +404,184 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent form of the same 8-phase tile loop: one workgroup per CU walks logical block ids b, b + gridDim.x, ... (the order
+// a one-tile-per-workgroup grid is dispatched in).  What it buys: the last K iteration of a tile stages the first six half-tiles
+// of the NEXT tile instead of the clamped re-loads the one-tile kernel issues there, so the next tile starts with its operands
+// in LDS (no workgroup dispatch, no exposed first-load latency: ~2.4 us of a ~23 us tile at K = 1024), and the epilogue's
+// stores drain under the next tile's first phases.  Operand addresses are a uniform panel base (SGPRs) + a per-lane 32-bit
+// offset that never changes, so walking tiles costs no VGPRs.  Whole interior tiles with a fast epilogue only (the launcher
+// checks).
+struct G8Panel { uint32_t a, b; };   // byte offsets of the A / W panels of one K tile inside their operands (uniform)
+
+// Buffer form of the LDS-DMA: voffset = the lane's fixed offset, soffset = the panel (SGPR) -- the addressing is explicit and
+// no 64-bit per-lane pointer exists (with global_load_lds hipcc sometimes materialises four of them and spills).
+__device__ __forceinline__ void g8p_stage(const __amdgpu_buffer_rsrc_t rs, char* slot, uint32_t panel, const uint32_t (&off)[2],
+                                          int wave_lds) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VMC_LDS void*)(slot + i * 8192 + wave_lds), 16, off[i], panel, 0, 0);
+}
+
+// vmcnt(8 + NS): the NS stores of the previous tile's epilogue sit in the (in-order) queue between the half-tiles staged before
+// the epilogue and those staged after it; they may stay outstanding through the first K tile (three waits), by the fourth wait
+// they are older than everything a wait needs and vmcnt(8) covers them.
+// In the first K tile of an output tile the queue also holds the bias DMA (one more operation, issued in front of phase 0's
+// stage): mode 0 = steady state, 1 = first K tile of the workgroup's first output tile, 2 = first K tile with stores pending.
+template <int NS>
+__device__ __forceinline__ void g8p_wait(int mode) {
+  if (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (mode == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (NS == 16) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+}
+
+// Two K tiles.  p1 / p2 / p3 = panels of K tiles t+1, t+2, t+3 (t+2 and t+3 may already belong to the next output tile).
+template <typename T, int NS>
+__device__ __forceinline__ void g8p_iter(char* __restrict__ A0e, char* __restrict__ A1e, char* __restrict__ B0e,
+                                         char* __restrict__ B1e, char* __restrict__ A0o, char* __restrict__ A1o,
+                                         char* __restrict__ B0o, char* __restrict__ B1o, const __amdgpu_buffer_rsrc_t ra,
+                                         const __amdgpu_buffer_rsrc_t rb, const G8Panel& p1, const G8Panel& p2,
+                                         const G8Panel& p3, uint32_t HA, uint32_t HB, const uint32_t (&oa)[2], const uint32_t (&ob)[2],
+                                         int wave_lds, const int (&xoff)[2], const int (&woff)[2][2], f32x4 (&acc)[2][2][4][2],
+                                         G8Frags<T>& f, int sp) {
+  // ---- even tile ----
+  g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
+  g8p_stage(rb, B1o, p1.b + HB, ob, wave_lds); g8p_wait<NS>(sp);
+  g8_mma<T>(acc[0][0], f.a, f.b0);
+  g8_read_b(B1e, woff, f.b1);
+  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<NS>(sp);
+  g8_mma<T>(acc[0][1], f.a, f.b1);
+  g8_read_a(A1e, xoff, f.a);
+  g8p_stage(ra, A0e, p2.a, oa, wave_lds);
+  g8_mma<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<NS>(sp);
+  g8_mma<T>(acc[1][0], f.a, f.b0);
+  // ---- odd tile ----
+  g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
+  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[0][0], f.a, f.b0);
+  g8_read_b(B1o, woff, f.b1);
+  g8p_stage(ra, A1e, p2.a + HA, oa, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[0][1], f.a, f.b1);
+  g8_read_a(A1o, xoff, f.a);
+  g8p_stage(ra, A0o, p3.a, oa, wave_lds);
+  g8_mma<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0o, p3.b, ob, wave_lds); G8_WAIT8();
+  g8_mma<T>(acc[1][0], f.a, f.b0);
+}
+
+template <typename T, int ACT, int EPI>
+__global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  const int ntiles = g.tiles_m * g.tiles_n;
+
+  uint32_t oa[2], ob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, ch;
+    stage_src_x(i * 512 + tid, row, ch);
+    oa[i] = (uint32_t)(row * g.lda + ch * 8) * 2u;
+    stage_src_w8(i * 512 + tid, row, ch);
+    ob[i] = (uint32_t)(row * g.ldw + ch * 8) * 2u;
+  }
+  const uint32_t HA = 128u * (uint32_t)g.lda * 2u, HB = 128u * (uint32_t)g.ldw * 2u;   // second half-tile (rows + 128)
+  const uint32_t TA = 2 * HA, TB = 2 * HB;                                              // one tile row / column panel
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, g.N * 4, 0x00020000);
+  const int wave_lds = wave * 1024;
+  int xoff[2], woff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    xoff[kk] = lds_off_x(64 * wm + r, 4 * kk + q);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) woff[kk][nt] = lds_off_w8(32 * wn + g8_w_row(r, nt), 4 * kk + q);
+  }
+  char* const A0e = smem + 0 * G8_SLOT; char* const A1e = smem + 1 * G8_SLOT;
+  char* const B0e = smem + 2 * G8_SLOT; char* const B1e = smem + 3 * G8_SLOT;
+  char* const A0o = smem + 4 * G8_SLOT; char* const A1o = smem + 5 * G8_SLOT;
+  char* const B0o = smem + 6 * G8_SLOT; char* const B1o = smem + 7 * G8_SLOT;
+
+  const int nkt = g.K >> 6;   // even, >= 2 (checked by the launcher)
+  int bid = blockIdx.x, tm, tn;
+  g8_tile_coords(g, xcd_remap(bid, ntiles), tm, tn);
+  G8Panel cur = {(uint32_t)tm * TA, (uint32_t)tn * TB};
+  // prologue of the first tile: same issue order as the steady state so the vmcnt accounting holds from the first phase
+  g8p_stage(ra, A0e, cur.a, oa, wave_lds); g8p_stage(rb, B0e, cur.b, ob, wave_lds); g8p_stage(rb, B1e, cur.b + HB, ob, wave_lds);
+  g8p_stage(ra, A1e, cur.a + HA, oa, wave_lds); g8p_stage(ra, A0o, cur.a + 128, oa, wave_lds); g8p_stage(rb, B0o, cur.b + 128, ob, wave_lds);
+  G8_WAIT8();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD by one barrier
+
+  constexpr int NS = EPI == G8_EPI_RES32 ? 32 : 16;    // stores per wave and tile
+  // The bias of a tile's 256 columns reaches the epilogue through LDS (1 KiB behind the operand slots, two buffers by tile
+  // parity): a global load in the epilogue would make the compiler wait for it with a vmcnt that also covers the next tile's
+  // freshly issued half-tiles (in-order counter) and expose their latency.  Each wave DMAs the 64 floats of its column quarter.
+  char* const bias_lds = smem + 8 * G8_SLOT;
+  const uint32_t bias_lane = (uint32_t)lane * 4u;
+  G8Frags<T> f;
+  int mode = 1, parity = 0;
+  for (;;) {
+    const int nbid = bid + (int)gridDim.x;
+    const bool has_next = nbid < ntiles;
+    int ntm = tm, ntn = tn;
+    if (has_next) g8_tile_coords(g, xcd_remap(nbid, ntiles), ntm, ntn);
+    // after the last tile the roll-over stages re-load this tile's last K tile (in bounds, never read)
+    const G8Panel nxt = has_next ? G8Panel{(uint32_t)ntm * TA, (uint32_t)ntn * TB}
+                                 : G8Panel{cur.a + (uint32_t)(nkt - 2) * 128u, cur.b + (uint32_t)(nkt - 2) * 128u};
+
+    f32x4 acc[2][2][4][2];  // [mh][nh][mt][nt]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nkt; t += 2) {
+      const bool roll = t + 2 >= nkt;
+      const G8Panel p1 = {cur.a + (uint32_t)(t + 1) * 128u, cur.b + (uint32_t)(t + 1) * 128u};
+      const G8Panel p2 = roll ? nxt : G8Panel{cur.a + (uint32_t)(t + 2) * 128u, cur.b + (uint32_t)(t + 2) * 128u};
+      const G8Panel p3 = roll ? G8Panel{nxt.a + 128u, nxt.b + 128u} : G8Panel{cur.a + (uint32_t)(t + 3) * 128u, cur.b + (uint32_t)(t + 3) * 128u};
+      if (t == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
+                                             (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
+      g8p_iter<T, NS>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, p1, p2, p3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, t == 0 ? mode : 0);
+    }
+    float bv[2][8];
+    {
+      uint4 braw[2][2];
+      const uint32_t bad = lds_addr(bias_lds + parity * 1024) + (uint32_t)(32 * wn + 8 * q) * 4u;
+      lds_read128<0>(braw[0][0], bad); lds_read128<16>(braw[0][1], bad);
+      lds_read128<512>(braw[1][0], bad); lds_read128<528>(braw[1][1], bad);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bv[nh][4 * h + 0] = __uint_as_float(braw[nh][h].x); bv[nh][4 * h + 1] = __uint_as_float(braw[nh][h].y);
+          bv[nh][4 * h + 2] = __uint_as_float(braw[nh][h].z); bv[nh][4 * h + 3] = __uint_as_float(braw[nh][h].w);
+        }
+    }
+    if constexpr (EPI == G8_EPI_STORE16) g8p_epilogue_store16<T, ACT>(g, acc, bv, tm * 256, tn * 256, wm, wn, r, q);
+    else g8p_epilogue_res32<T, ACT>(g, acc, bv, tm * 256, tn * 256, wm, wn, r, q);
+    if (!has_next) break;
+    mode = 2; parity ^= 1;
+    bid = nbid; tm = ntm; tn = ntn; cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must land before exit
+  if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
+}
+
 template <typename T, int ACT>
 static int g8_launch(GemmArgs& g, hipStream_t stream) {
   auto kern = gemm8_kernel<T, ACT>;
@@ -335,13 +598,51 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
+template <typename T, int ACT, int EPI>
+static int g8p_launch(GemmArgs& g, hipStream_t stream) {
+  auto kern = gemm8p_kernel<T, ACT, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT + 2048);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  g.tiles_m = g.M / 256;
+  g.tiles_n = g.N / 256;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * G8_SLOT + 2048, stream, g);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+// The persistent kernel takes problems made of whole 256x256 tiles (at least one per CU) whose epilogue is one of the two
+// fast forms; a pre-activation side output doubles the stores per tile, which the vmcnt accounting does not cover.
+static bool g8p_eligible(const GemmArgs& g) {
+  if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 256) return false;
+  if ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.ldw * 2 >= (1ull << 32)) return false;   // 32-bit lane offsets
+  const int kind = g8_epi_kind(g);
+  if (!g.bias) return false;   // the bias travels through LDS and is part of the vmcnt accounting
+  return (kind == G8_EPI_STORE16 && !g.zout) || kind == G8_EPI_RES32;
+}
+
+template <typename T, int ACT>
+static int g8_pick(GemmArgs& g, hipStream_t s) {
+  // Measured (profiles/README.md, round 2): the persistent walk pays on the 16-bit-output shapes (c_fc +3 %, qkv +1 %); with
+  // the fp32 residual epilogue its loads queue behind the previous batch's stores and it is 1-2 % slower -> one-tile kernel.
+  if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) {
+    const int kind = g8_epi_kind(g);
+    if (kind == G8_EPI_STORE16) return g8p_launch<T, ACT, G8_EPI_STORE16>(g, s);
+    if (g.variant == VMC_GEMM_PERSISTENT) return g8p_launch<T, ACT, G8_EPI_RES32>(g, s);
+  }
+  return g8_launch<T, ACT>(g, s);
+}
+
 template <typename T>
 static int g8_act(GemmArgs& g, int act, hipStream_t s) {
   switch (act) {
-    case VMC_ACT_NONE: return g8_launch<T, VMC_ACT_NONE>(g, s);
-    case VMC_ACT_QUICKGELU: return g8_launch<T, VMC_ACT_QUICKGELU>(g, s);
-    case VMC_ACT_GELU_ERF: return g8_launch<T, VMC_ACT_GELU_ERF>(g, s);
-    case VMC_ACT_RELU: return g8_launch<T, VMC_ACT_RELU>(g, s);
+    case VMC_ACT_NONE: return g8_pick<T, VMC_ACT_NONE>(g, s);
+    case VMC_ACT_QUICKGELU: return g8_pick<T, VMC_ACT_QUICKGELU>(g, s);
+    case VMC_ACT_GELU_ERF: return g8_pick<T, VMC_ACT_GELU_ERF>(g, s);
+    case VMC_ACT_RELU: return g8_pick<T, VMC_ACT_RELU>(g, s);
   }
   return VMC_E_ARG;
 }
