@@ -11,9 +11,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vimo_clip_amd import ops  # noqa: E402
 
-CASES = [  # M, N, K, act, res32
-    (65792, 4096, 1024, 1, False), (65792, 3072, 1024, 0, False), (65792, 1024, 1024, 0, True), (65792, 1024, 4096, 0, True),
-    (16384, 4096, 256, 0, False), (8192, 8192, 512, 3, False), (25600, 3072, 768, 0, False), (25600, 768, 3072, 0, True),
+CASES = [  # M, N, K, act, res32 (the persistent kernel takes the 16-bit-output ones; the fp32-residual ones stay one-tile)
+    (65792, 4096, 1024, 1, False), (65792, 3072, 1024, 0, False), (65792, 1024, 1024, 0, False), (65792, 1024, 4096, 0, False),
+    (16384, 4096, 256, 0, False), (8192, 8192, 512, 3, False), (25600, 3072, 768, 0, False), (65536, 256, 384, 1, False),
+    (65792, 1024, 1024, 0, True),
 ]
 
 
@@ -47,7 +48,7 @@ def main():
     print("mismatches:", bad, flush=True)
     if bad:
         sys.exit(1)
-    for (M, N, K, act, res32) in CASES[:4]:
+    for (M, N, K, act, res32) in CASES[:4] + CASES[-1:]:
         dt = torch.bfloat16
         a = torch.randn(M, K, device="cuda").to(dt)
         w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)

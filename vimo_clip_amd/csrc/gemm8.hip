@@ -127,78 +127,36 @@ __device__ __forceinline__ void g8_nt_store(const uint4& o, uint16_t* dst) {
   __builtin_nontemporal_store((g8_u32x4){o.x, o.y, o.z, o.w}, (g8_u32x4*)dst);
 }
 
-// ---- fast epilogues of an interior 256x256 tile (shared by the one-tile and the persistent kernel) ----
-// 16-bit rows without residual / row remap (qkv, c_fc, dgrad): branch-free, the bias of this lane's 2 x 8 columns loaded once
-// instead of once per row (the generic path cannot hoist it past the stores).  16 stores per wave (32 with a pre-activation
-// side output).  Output stores are non-temporal: the tensor (400 .. 540 MB per ViT-L/14 launch) is larger than the Infinity
-// Cache and is read next by another kernel; +1.2 .. 1.5 % on the qkv / c_fc shapes.  Staging the tile through LDS for whole-row
-// stores was measured too and does not pay (profiles/README.md, round 2).
-template <typename T, int ACT>
-__device__ __forceinline__ void g8p_epilogue_store16(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], const float (&bv)[2][8], int m0,
-                                                    int n0, int wm, int wn, int r, int q) {
-  char* const ctile = g.C + ((size_t)m0 * g.ldc + n0) * 2;
-  uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 2u;
-  asm volatile("" : "+v"(clane));   // the 16 row offsets are formed here, not hoisted above the K loop
+// ---- epilogue of the persistent kernel: one accumulator QUADRANT (128 rows x 128 columns of the tile; 32 registers, 4 stores per
+// wave) at a time, bias from LDS, then the quadrant is zeroed for the next tile.  Addresses are a uniform tile base plus a 32-bit
+// per-lane offset; the offset is laundered through an empty asm so that hipcc forms the four row offsets here instead of keeping
+// sixteen of them live across the K loop.  Output stores are non-temporal (the tensor, 400 .. 540 MB per ViT-L/14 launch, is
+// larger than the Infinity Cache and is read next by another kernel).
+template <typename T, int ACT, int MH, int NH>
+__device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[4][2], char* ctile, uint32_t clane, uint32_t bias_ad) {
+  uint4 braw[2];
+  lds_read128<512 * NH>(braw[0], bias_ad);
+  lds_read128<512 * NH + 16>(braw[1], bias_ad);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const float bv[8] = {__uint_as_float(braw[0].x), __uint_as_float(braw[0].y), __uint_as_float(braw[0].z), __uint_as_float(braw[0].w),
+                       __uint_as_float(braw[1].x), __uint_as_float(braw[1].y), __uint_as_float(braw[1].z), __uint_as_float(braw[1].w)};
+  uint32_t cl = clane;
+  asm volatile("" : "+v"(cl));
 #pragma unroll
-  for (int mh = 0; mh < 2; ++mh)
+  for (int mt = 0; mt < 4; ++mt) {
+    float v[8];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        float v[8];
+      for (int j = 0; j < 4; ++j) v[4 * nt + j] = aq[mt][nt][j] + bv[4 * nt + j];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+    for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
+    g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
+                (uint16_t*)(ctile + (cl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * NH)));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mh][nh][mt][nt][j] + bv[nh][4 * nt + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
-        g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
-                    (uint16_t*)(ctile + (clane + (uint32_t)(128 * mh + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * nh)));
-      }
-}
-
-// Accumulate into an fp32 residual stream (x += A W^T + b; out_proj / c_proj): the residual rows of four tile rows are
-// fetched together (8 x 32 B per lane in flight), then added and stored; no per-row branches.  32 stores per wave.
-template <typename T, int ACT>
-__device__ __forceinline__ void g8p_epilogue_res32(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], const float (&bv)[2][8], int m0,
-                                                  int n0, int wm, int wn, int r, int q) {
-  const char* const rtile = g.res + ((size_t)m0 * g.ldres + n0) * 4;
-  char* const ctile = g.C + ((size_t)m0 * g.ldc + n0) * 4;
-  uint32_t rlane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldres + 32 * wn + 8 * q) * 4u;
-  uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 4u;
-  asm volatile("" : "+v"(rlane), "+v"(clane));   // the row offsets are formed here, not hoisted above the K loop
-#pragma unroll
-  for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-    for (int mp = 0; mp < 2; ++mp) {             // two tile rows per batch: 8 x 32 B per lane in flight, 32 registers
-      float4 rr[2][2][2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-          const float* src = (const float*)(rtile + (rlane + (uint32_t)(128 * mh + 16 * (2 * mp + mi)) * (uint32_t)g.ldres * 4u + 512u * nh));
-          rr[mi][nh][0] = *(const float4*)src;
-          rr[mi][nh][1] = *(const float4*)(src + 4);
-        }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-          const int mt = 2 * mp + mi;
-          float* dst = (float*)(ctile + (clane + (uint32_t)(128 * mh + 16 * mt) * (uint32_t)g.ldc * 4u + 512u * nh));
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const float4 x = rr[mi][nh][nt];
-            float4 o;
-            o.x = x.x + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][0] + bv[nh][4 * nt + 0]);
-            o.y = x.y + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][1] + bv[nh][4 * nt + 1]);
-            o.z = x.z + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][2] + bv[nh][4 * nt + 2]);
-            o.w = x.w + g.alpha * apply_act<ACT>(acc[mh][nh][mt][nt][3] + bv[nh][4 * nt + 3]);
-            *(float4*)(dst + 4 * nt) = o;
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int nt = 0; nt < 2; ++nt) aq[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // Which fast epilogue the whole problem qualifies for (tile interior checked by the caller).
@@ -406,16 +364,19 @@ __global__ void __launch_bounds__(512, 2) gemm8_kernel(const GemmArgs g) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Persistent form of the same 8-phase tile loop: one workgroup per CU walks logical block ids b, b + gridDim.x, ... (the order
-// a one-tile-per-workgroup grid is dispatched in).  What it buys: the last K iteration of a tile stages the first six half-tiles
-// of the NEXT tile instead of the clamped re-loads the one-tile kernel issues there, so the next tile starts with its operands
-// in LDS (no workgroup dispatch, no exposed first-load latency: ~2.4 us of a ~23 us tile at K = 1024), and the epilogue's
-// stores drain under the next tile's first phases.  Operand addresses are a uniform panel base (SGPRs) + a per-lane 32-bit
-// offset that never changes, so walking tiles costs no VGPRs.  Whole interior tiles with a fast epilogue only (the launcher
-// checks).
+// a one-tile-per-workgroup grid is dispatched in).  Two things are taken off the ~8 us a tile spends outside its K loop:
+//  * the last K iteration of a tile stages the first six half-tiles of the NEXT tile instead of the clamped re-loads the
+//    one-tile kernel issues there, so the next tile starts with its operands in LDS (no dispatch, no exposed first-load latency);
+//  * the epilogue runs per accumulator quadrant in the phases where the quadrant is final and not yet rewritten, in the slot of
+//    a phase where this wave would otherwise sit at the barrier while its SIMD partner runs the MFMA cluster: quadrant (0,0) is
+//    final after phase 0 of the last K tile and is rewritten by phase 0 of the next tile, (0,1) one phase later, ... :
+//        last K tile, phase 1: (0,0)   phase 2: (0,1)   phase 3: (1,1)      next tile, phase 0: (1,0)
+//    Conversions and stores overlap the partner's MFMAs; no accumulator is live twice and none is zeroed on the critical path.
+// Operand addresses are buffer offsets: voffset = the lane's fixed offset, soffset = the panel (SGPR), so walking tiles costs no
+// VGPRs and no 64-bit per-lane pointer exists (with global_load_lds hipcc sometimes materialises four of them and spills).
+// Whole interior tiles, 16-bit output with bias, K >= 256 only (the launcher checks).
 struct G8Panel { uint32_t a, b; };   // byte offsets of the A / W panels of one K tile inside their operands (uniform)
 
-// Buffer form of the LDS-DMA: voffset = the lane's fixed offset, soffset = the panel (SGPR) -- the addressing is explicit and
-// no 64-bit per-lane pointer exists (with global_load_lds hipcc sometimes materialises four of them and spills).
 __device__ __forceinline__ void g8p_stage(const __amdgpu_buffer_rsrc_t rs, char* slot, uint32_t panel, const uint32_t (&off)[2],
                                           int wave_lds) {
 #pragma unroll
@@ -423,55 +384,72 @@ __device__ __forceinline__ void g8p_stage(const __amdgpu_buffer_rsrc_t rs, char*
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VMC_LDS void*)(slot + i * 8192 + wave_lds), 16, off[i], panel, 0, 0);
 }
 
-// vmcnt(8 + NS): the NS stores of the previous tile's epilogue sit in the (in-order) queue between the half-tiles staged before
-// the epilogue and those staged after it; they may stay outstanding through the first K tile (three waits), by the fourth wait
-// they are older than everything a wait needs and vmcnt(8) covers them.
-// In the first K tile of an output tile the queue also holds the bias DMA (one more operation, issued in front of phase 0's
-// stage): mode 0 = steady state, 1 = first K tile of the workgroup's first output tile, 2 = first K tile with stores pending.
-template <int NS>
-__device__ __forceinline__ void g8p_wait(int mode) {
-  if (mode == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (mode == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (NS == 16) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+// The vmcnt queue is in order and also carries the epilogue stores and the bias DMA, so "all but the four youngest half-tiles
+// have landed" is a different count per iteration kind:
+//   G8P_STEADY  every wait 8
+//   G8P_ROLL    last iteration of a tile: 4 stores follow the stage of odd phases 1, 2, 3     -> odd waits 8, 8+4, 8+12
+//   G8P_HEAD    first iteration of the workgroup's first tile: the bias DMA sits in front of phase 0's stage
+//                                                                                             -> even waits 9, 9, 9
+//   G8P_HEAD    (pending) first iteration of a later tile: 12 stores + bias DMA + 4 stores (quadrant (1,0), after phase 0's stage)
+//                                                                                -> even waits 25, 25, 17; odd phase 0: 12
+// (derivation: count the operations younger than the half-tile the wait must retire)
+// The iteration kind is a template parameter (three copies of the loop body: head, steady, roll): selecting the count at run
+// time costs 3-5 scalar branches per wait, ~200 cycles per K tile (measured: -6.7 % at K = 4096).  Only the head copy, run once
+// per tile, keeps a run-time choice (first tile of the workgroup or not).
+enum { G8P_STEADY = 0, G8P_ROLL = 1, G8P_HEAD = 2 };
+template <int KIND, int S, int R, int F, int N>
+__device__ __forceinline__ void g8p_wait(bool pending) {
+  if constexpr (KIND == G8P_STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+  else if constexpr (KIND == G8P_ROLL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory");
+  else if (pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(F) : "memory");
 }
 
 // Two K tiles.  p1 / p2 / p3 = panels of K tiles t+1, t+2, t+3 (t+2 and t+3 may already belong to the next output tile).
-template <typename T, int NS>
-__device__ __forceinline__ void g8p_iter(char* __restrict__ A0e, char* __restrict__ A1e, char* __restrict__ B0e,
+// fin_c / fin_b = uniform output base and LDS bias address of the tile whose quadrants are written here: the current tile in a
+// G8P_ROLL iteration, the previous one in a pending G8P_HEAD (clane = this lane's offset inside an output tile).
+template <typename T, int ACT, int KIND>
+__device__ __forceinline__ void g8p_iter(const GemmArgs& g, char* __restrict__ A0e, char* __restrict__ A1e, char* __restrict__ B0e,
                                          char* __restrict__ B1e, char* __restrict__ A0o, char* __restrict__ A1o,
                                          char* __restrict__ B0o, char* __restrict__ B1o, const __amdgpu_buffer_rsrc_t ra,
                                          const __amdgpu_buffer_rsrc_t rb, const G8Panel& p1, const G8Panel& p2,
                                          const G8Panel& p3, uint32_t HA, uint32_t HB, const uint32_t (&oa)[2], const uint32_t (&ob)[2],
                                          int wave_lds, const int (&xoff)[2], const int (&woff)[2][2], f32x4 (&acc)[2][2][4][2],
-                                         G8Frags<T>& f, int sp) {
+                                         G8Frags<T>& f, bool pending, char* fin_c, uint32_t clane, uint32_t fin_b) {
   // ---- even tile ----
   g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
-  g8p_stage(rb, B1o, p1.b + HB, ob, wave_lds); g8p_wait<NS>(sp);
+  g8p_stage(rb, B1o, p1.b + HB, ob, wave_lds);
+  if (KIND == G8P_HEAD && pending) g8p_fin_quadrant<T, ACT, 1, 0>(g, acc[1][0], fin_c, clane, fin_b);
+  g8p_wait<KIND, 8, 8, 9, 25>(pending);
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1e, woff, f.b1);
-  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<NS>(sp);
+  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<KIND, 8, 8, 9, 25>(pending);
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1e, xoff, f.a);
   g8p_stage(ra, A0e, p2.a, oa, wave_lds);
   g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<NS>(sp);
+  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<KIND, 8, 8, 9, 17>(pending);
   g8_mma<T>(acc[1][0], f.a, f.b0);
   // ---- odd tile ----
   g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
-  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); G8_WAIT8();
+  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); g8p_wait<KIND, 8, 8, 8, 12>(pending);
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1o, woff, f.b1);
-  g8p_stage(ra, A1e, p2.a + HA, oa, wave_lds); G8_WAIT8();
+  g8p_stage(ra, A1e, p2.a + HA, oa, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 0, 0>(g, acc[0][0], fin_c, clane, fin_b);
+  g8p_wait<KIND, 8, 12, 8, 8>(pending);
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1o, xoff, f.a);
   g8p_stage(ra, A0o, p3.a, oa, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 0, 1>(g, acc[0][1], fin_c, clane, fin_b);
   g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8p_stage(rb, B0o, p3.b, ob, wave_lds); G8_WAIT8();
+  g8p_stage(rb, B0o, p3.b, ob, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 1, 1>(g, acc[1][1], fin_c, clane, fin_b);
+  g8p_wait<KIND, 8, 20, 8, 8>(pending);
   g8_mma<T>(acc[1][0], f.a, f.b0);
 }
 
-template <typename T, int ACT, int EPI>
+template <typename T, int ACT>
 __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -507,8 +485,15 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   char* const B0e = smem + 2 * G8_SLOT; char* const B1e = smem + 3 * G8_SLOT;
   char* const A0o = smem + 4 * G8_SLOT; char* const A1o = smem + 5 * G8_SLOT;
   char* const B0o = smem + 6 * G8_SLOT; char* const B1o = smem + 7 * G8_SLOT;
+  // The bias of a tile's 256 columns reaches its epilogue through LDS (1 KiB behind the operand slots, two buffers by tile
+  // parity): a global load in the epilogue would make the compiler wait for it with a vmcnt that also covers the freshly
+  // issued half-tiles (in-order counter) and expose their latency.  Each wave DMAs the 64 floats of its column quarter.
+  char* const bias_lds = smem + 8 * G8_SLOT;
+  const uint32_t bias_lane = (uint32_t)lane * 4u;
+  const uint32_t bias_ad0 = lds_addr(bias_lds) + (uint32_t)(32 * wn + 8 * q) * 4u;
+  const uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 2u;
 
-  const int nkt = g.K >> 6;   // even, >= 2 (checked by the launcher)
+  const int nkt = g.K >> 6;   // even, >= 4 (checked by the launcher)
   int bid = blockIdx.x, tm, tn;
   g8_tile_coords(g, xcd_remap(bid, ntiles), tm, tn);
   G8Panel cur = {(uint32_t)tm * TA, (uint32_t)tn * TB};
@@ -519,65 +504,57 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD by one barrier
 
-  constexpr int NS = EPI == G8_EPI_RES32 ? 32 : 16;    // stores per wave and tile
-  // The bias of a tile's 256 columns reaches the epilogue through LDS (1 KiB behind the operand slots, two buffers by tile
-  // parity): a global load in the epilogue would make the compiler wait for it with a vmcnt that also covers the next tile's
-  // freshly issued half-tiles (in-order counter) and expose their latency.  Each wave DMAs the 64 floats of its column quarter.
-  char* const bias_lds = smem + 8 * G8_SLOT;
-  const uint32_t bias_lane = (uint32_t)lane * 4u;
+  f32x4 acc[2][2][4][2];  // [mh][nh][mt][nt]; zero here, afterwards every quadrant epilogue leaves its quadrant zeroed
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
   G8Frags<T> f;
-  int mode = 1, parity = 0;
+  int parity = 0;
+  char* prev_c = nullptr;                     // the tile whose quadrant (1,0) is still to be written: output base ...
+  uint32_t prev_b = bias_ad0;                 // ... and LDS address of its bias
   for (;;) {
     const int nbid = bid + (int)gridDim.x;
     const bool has_next = nbid < ntiles;
     int ntm = tm, ntn = tn;
     if (has_next) g8_tile_coords(g, xcd_remap(nbid, ntiles), ntm, ntn);
-    // after the last tile the roll-over stages re-load this tile's last K tile (in bounds, never read)
+    // after the last tile the roll-over stages re-load this tile's last K tiles (in bounds, never read)
     const G8Panel nxt = has_next ? G8Panel{(uint32_t)ntm * TA, (uint32_t)ntn * TB}
                                  : G8Panel{cur.a + (uint32_t)(nkt - 2) * 128u, cur.b + (uint32_t)(nkt - 2) * 128u};
+    char* const here_c = g.C + ((size_t)tm * 256 * g.ldc + (size_t)tn * 256) * 2;
+    const uint32_t here_b = bias_ad0 + (uint32_t)parity * 1024u;
 
-    f32x4 acc[2][2][4][2];  // [mh][nh][mt][nt]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int t = 0; t < nkt; t += 2) {
-      const bool roll = t + 2 >= nkt;
+#define G8P_ITER(KIND, P1, P2, P3, PEND, FC, FB) \
+  g8p_iter<T, ACT, KIND>(g, A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, P1, P2, P3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, PEND, FC, clane, FB)
+    {  // head: K tiles 0, 1 (already staged); stages 1, 2, 3; the previous tile's quadrant (1,0) goes out in phase 0
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
+                                               (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
+      const G8Panel p1 = {cur.a + 128u, cur.b + 128u}, p2 = {cur.a + 256u, cur.b + 256u}, p3 = {cur.a + 384u, cur.b + 384u};
+      G8P_ITER(G8P_HEAD, p1, p2, p3, prev_c != nullptr, prev_c, prev_b);
+    }
+    for (int t = 2; t + 2 < nkt; t += 2) {
       const G8Panel p1 = {cur.a + (uint32_t)(t + 1) * 128u, cur.b + (uint32_t)(t + 1) * 128u};
-      const G8Panel p2 = roll ? nxt : G8Panel{cur.a + (uint32_t)(t + 2) * 128u, cur.b + (uint32_t)(t + 2) * 128u};
-      const G8Panel p3 = roll ? G8Panel{nxt.a + 128u, nxt.b + 128u} : G8Panel{cur.a + (uint32_t)(t + 3) * 128u, cur.b + (uint32_t)(t + 3) * 128u};
-      if (t == 0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
-                                             (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
-      g8p_iter<T, NS>(A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, p1, p2, p3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, t == 0 ? mode : 0);
+      const G8Panel p2 = {cur.a + (uint32_t)(t + 2) * 128u, cur.b + (uint32_t)(t + 2) * 128u};
+      const G8Panel p3 = {cur.a + (uint32_t)(t + 3) * 128u, cur.b + (uint32_t)(t + 3) * 128u};
+      G8P_ITER(G8P_STEADY, p1, p2, p3, false, here_c, here_b);
     }
-    float bv[2][8];
-    {
-      uint4 braw[2][2];
-      const uint32_t bad = lds_addr(bias_lds + parity * 1024) + (uint32_t)(32 * wn + 8 * q) * 4u;
-      lds_read128<0>(braw[0][0], bad); lds_read128<16>(braw[0][1], bad);
-      lds_read128<512>(braw[1][0], bad); lds_read128<528>(braw[1][1], bad);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          bv[nh][4 * h + 0] = __uint_as_float(braw[nh][h].x); bv[nh][4 * h + 1] = __uint_as_float(braw[nh][h].y);
-          bv[nh][4 * h + 2] = __uint_as_float(braw[nh][h].z); bv[nh][4 * h + 3] = __uint_as_float(braw[nh][h].w);
-        }
+    {  // roll: K tiles nkt-2, nkt-1; stages the next tile's K tiles 0 and 1; quadrants (0,0), (0,1), (1,1) of this tile go out
+      const G8Panel p1 = {cur.a + (uint32_t)(nkt - 1) * 128u, cur.b + (uint32_t)(nkt - 1) * 128u};
+      const G8Panel p3 = {nxt.a + 128u, nxt.b + 128u};
+      G8P_ITER(G8P_ROLL, p1, nxt, p3, false, here_c, here_b);
     }
-    if constexpr (EPI == G8_EPI_STORE16) g8p_epilogue_store16<T, ACT>(g, acc, bv, tm * 256, tn * 256, wm, wn, r, q);
-    else g8p_epilogue_res32<T, ACT>(g, acc, bv, tm * 256, tn * 256, wm, wn, r, q);
+#undef G8P_ITER
+    prev_c = here_c; prev_b = here_b;
     if (!has_next) break;
-    mode = 2; parity ^= 1;
+    parity ^= 1;
     bid = nbid; tm = ntm; tn = ntn; cur = nxt;
   }
+  g8p_fin_quadrant<T, ACT, 1, 0>(g, acc[1][0], prev_c, clane, prev_b);   // last tile's last quadrant
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must land before exit
   if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
 }
@@ -598,9 +575,9 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
-template <typename T, int ACT, int EPI>
+template <typename T, int ACT>
 static int g8p_launch(GemmArgs& g, hipStream_t stream) {
-  auto kern = gemm8p_kernel<T, ACT, EPI>;
+  auto kern = gemm8p_kernel<T, ACT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT + 2048);
@@ -614,25 +591,21 @@ static int g8p_launch(GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
-// The persistent kernel takes problems made of whole 256x256 tiles (at least one per CU) whose epilogue is one of the two
-// fast forms; a pre-activation side output doubles the stores per tile, which the vmcnt accounting does not cover.
+// The persistent kernel takes problems made of whole 256x256 tiles (at least one per CU, at least two K iterations) with a
+// bias and a plain 16-bit output (qkv / out_proj / c_fc / c_proj of the encoders); everything else -- fp32 residual epilogue,
+// pre-activation side output, row remaps, no bias (dgrad) -- runs one tile per workgroup.
 static bool g8p_eligible(const GemmArgs& g) {
-  if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 256) return false;
-  if ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.ldw * 2 >= (1ull << 32)) return false;   // 32-bit lane offsets
-  const int kind = g8_epi_kind(g);
-  if (!g.bias) return false;   // the bias travels through LDS and is part of the vmcnt accounting
-  return (kind == G8_EPI_STORE16 && !g.zout) || kind == G8_EPI_RES32;
+  if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 256 || g.K < 256) return false;
+  if ((size_t)g.M * g.lda * 2 >= (1ull << 31) || (size_t)g.N * g.ldw * 2 >= (1ull << 31)) return false;   // buffer descriptors / 32-bit offsets
+  if ((size_t)255 * g.ldc * 2 + 512 >= (1ull << 31)) return false;
+  return g.bias && !g.zout && g8_epi_kind(g) == G8_EPI_STORE16;
 }
 
 template <typename T, int ACT>
 static int g8_pick(GemmArgs& g, hipStream_t s) {
-  // Measured (profiles/README.md, round 2): the persistent walk pays on the 16-bit-output shapes (c_fc +3 %, qkv +1 %); with
-  // the fp32 residual epilogue its loads queue behind the previous batch's stores and it is 1-2 % slower -> one-tile kernel.
-  if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) {
-    const int kind = g8_epi_kind(g);
-    if (kind == G8_EPI_STORE16) return g8p_launch<T, ACT, G8_EPI_STORE16>(g, s);
-    if (g.variant == VMC_GEMM_PERSISTENT) return g8p_launch<T, ACT, G8_EPI_RES32>(g, s);
-  }
+  // erf-GELU: hipcc spills four registers in the persistent kernel, and scratch accesses count in vmcnt -> one-tile kernel
+  if constexpr (ACT != VMC_ACT_GELU_ERF)
+    if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) return g8p_launch<T, ACT>(g, s);
   return g8_launch<T, ACT>(g, s);
 }
 
