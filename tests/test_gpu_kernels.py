@@ -46,6 +46,39 @@ def test_linear_exact_integers(ops, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,act", [
+    (65536, 256, 256, 0),        # 256 tiles, one per workgroup: head + roll iterations only (K = 4 K tiles)
+    (16384, 4096, 384, 1),       # 1024 tiles = 4 per workgroup, head / steady / roll, QuickGELU
+    (65792, 1024, 512, 3),       # ViT-L/14 row count: 1024 persistent tiles + the 256-row tail launch, ReLU
+    (8192, 8192, 1024, 0),       # 1024 tiles, 16 K tiles
+])
+def test_linear_persistent_walk(ops, dtype, M, N, K, act):
+    """Persistent 8-phase GEMM (whole 256x256 tiles, bias, 16-bit output: what vmc_linear takes for the encoder's big linears).
+    (1) integer operands: exact against the fp32 CPU product for every tile a workgroup walks (a wrong prefetch / a quadrant
+    stored before its last MFMA shows as wrong values); (2) random operands: bit-identical to the one-tile-per-workgroup kernel
+    (VMC_GEMM_ONE_TILE) on repeated launches -- the vmcnt accounting differs per iteration kind, a race shows as rare tiles."""
+    if act != 1:
+        a = _ints((M, K), -1, 1, 11)
+        w = _ints((N, K), -1, 1, 12)
+        w[:, 0] += torch.arange(N).float() % 3
+        a[:, 1] += torch.arange(M).float() % 2
+        bias = (torch.arange(N).float() % 7) - 3
+        z = (a.to(DEV) @ w.to(DEV).t() + bias.to(DEV))
+        z = torch.relu(z) if act == 3 else z
+        assert z.abs().max().item() <= 256             # integers up to 256 are exact in bf16 and f16
+        out = ops.linear(a.to(DEV, dtype), w.to(DEV, dtype), bias=bias.to(DEV), act=act, out_dtype=dtype)
+        assert torch.equal(out.float(), z), f"max diff {(out.float() - z).abs().max()}"
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    ar = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    wr = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(dtype)
+    br = torch.randn(N, device=DEV, generator=g)
+    ref = ops.linear(ar, wr, bias=br, act=act, alpha=0.75, out_dtype=dtype, variant=4)      # VMC_GEMM_ONE_TILE
+    for _ in range(3):
+        got = ops.linear(ar, wr, bias=br, act=act, alpha=0.75, out_dtype=dtype)              # default: persistent walk
+        assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("res_f32,out_f32", [(True, True), (False, False), (True, False)])
 @pytest.mark.parametrize("shape", [(333, 200, 128), (3900, 4096, 256)], ids=["small", "g8"])
