@@ -581,7 +581,7 @@ def main():
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE of one [65792,1024]x[1024,4096] launch (profiles/r02_gemm8_traffic.json); algorithmic bytes 6.8e8",
-                "kernel": "gemm8_kernel<BF16,*> (vmc_linear 8-phase 256x256x64 tiles), all large-GEMM launches of the step", "launches": len(big),
+                "kernel": "gemm8p_kernel<BF16,*> (vmc_linear: persistent walk of 8-phase 256x256x64 tiles; gemm8_kernel for the few non-eligible launches), all large-GEMM launches of the step", "launches": len(big),
                 "avg_launch_ms": round(1e3 * t_big / max(1, len(big)), 4),
                 "note": "algorithmic FLOPs = 2*M*N*K (K incl. zero padding 588->640 of the patch GEMM) per launch",
             }

@@ -7,12 +7,17 @@ timeout -k 10 500 python3 bench.py > $O/bench_line.json 2> $O/bench.err
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/ks.log 2>&1
 find $O/ks -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
 rm -rf $O/ks
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -- python3 tools/gemm_bench.py --shapes 65792,4096,1024 --act 1 --iters 3 --rounds 1 > $O/pmc_$n.log 2>&1
 done
-python3 tools/pmc_summary.py gemm8_kernel $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum > $O/gemm8_pmc.txt
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum
+python3 tools/pmc_summary.py gemm8p_kernel $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $O/gemm8_pmc.txt
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
+# encoder step alone (no secondary legs) and the persistent / one-tile A/B with its bit-equality screen
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/es -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/es.log 2>&1
+find $O/es -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/encoder_step_kernel_stats.csv
+rm -rf $O/es
+timeout -k 10 300 python3 tools/gemm_persist_check.py --repeats 5 > $O/gemm_persistent_vs_one_tile.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tf -- python3 tools/tfam_chain_run.py 8 100 > $O/tf.log 2>&1
 find $O/tf -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/tfam_chain_B8_kernel_stats.csv
 rm -rf $O/tf
