@@ -58,3 +58,26 @@ def test_no_cpu_fallback_for_host_tensors():
     from vimo_clip_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.linear(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+def test_persistent_gemm_kernels_use_no_scratch():
+    """gemm8p_kernel counts the operations in its vmcnt queue by hand (vimo_clip_amd/csrc/gemm8.hip, `g8p_wait`): a register
+    spill would add scratch loads / stores -- VMEM operations -- to that queue.  The Makefile keeps hipcc's resource-usage
+    remarks of gemm8.hip; every persistent instantiation must report no scratch and no spilled VGPR."""
+    import re
+    path = os.path.join(ROOT, "vimo_clip_amd", "csrc", "build", "gemm8.usage.txt")
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    text = open(path).read()
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "gemm8p_kernel" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        assert scratch == 0 and spills == 0, (name, scratch, spills)
+    assert seen >= 10, seen

@@ -76,6 +76,17 @@ def test_linear_persistent_walk(ops, dtype, M, N, K, act):
     for _ in range(3):
         got = ops.linear(ar, wr, bias=br, act=act, alpha=0.75, out_dtype=dtype)              # default: persistent walk
         assert torch.equal(got, ref)
+    if act == 0:        # bias-free instantiation (input-gradient GEMMs of training)
+        ref = ops.linear(ar, wr, out_dtype=dtype, variant=4)
+        for _ in range(3):
+            assert torch.equal(ops.linear(ar, wr, out_dtype=dtype), ref)
+    if act == 1:        # pre-activation side output (training forward of QuickGELU linears): 8 stores per quadrant
+        z_ref = ops.linear(ar, wr, bias=br, out_dtype=dtype, variant=4)              # the value before the activation
+        y_ref = ops.linear(ar, wr, bias=br, act=1, out_dtype=dtype, variant=4)
+        for _ in range(3):
+            z = torch.zeros(M, N, device=DEV, dtype=dtype)
+            y = ops.linear(ar, wr, bias=br, act=1, out_dtype=dtype, z_out=z)
+            assert torch.equal(y, y_ref) and torch.equal(z, z_ref)
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])

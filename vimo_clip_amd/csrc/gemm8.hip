@@ -132,17 +132,25 @@ __device__ __forceinline__ void g8_nt_store(const uint4& o, uint16_t* dst) {
 // per-lane offset; the offset is laundered through an empty asm so that hipcc forms the four row offsets here instead of keeping
 // sixteen of them live across the K loop.  Output stores are non-temporal (the tensor, 400 .. 540 MB per ViT-L/14 launch, is
 // larger than the Infinity Cache and is read next by another kernel).
-template <typename T, int ACT, int MH, int NH>
-__device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[4][2], char* ctile, uint32_t clane, uint32_t bias_ad) {
-  uint4 braw[2];
-  lds_read128<512 * NH>(braw[0], bias_ad);
-  lds_read128<512 * NH + 16>(braw[1], bias_ad);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  const float bv[8] = {__uint_as_float(braw[0].x), __uint_as_float(braw[0].y), __uint_as_float(braw[0].z), __uint_as_float(braw[0].w),
-                       __uint_as_float(braw[1].x), __uint_as_float(braw[1].y), __uint_as_float(braw[1].z), __uint_as_float(braw[1].w)};
+template <typename T, int ACT, bool BIAS, bool ZOUT, int MH, int NH>
+__device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[4][2], char* ctile, char* ztile, uint32_t clane, uint32_t zlane,
+                                                 uint32_t bias_ad) {
+  float bv[8];
+  if constexpr (BIAS) {
+    uint4 braw[2];
+    lds_read128<512 * NH>(braw[0], bias_ad);
+    lds_read128<512 * NH + 16>(braw[1], bias_ad);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bv[0] = __uint_as_float(braw[0].x); bv[1] = __uint_as_float(braw[0].y); bv[2] = __uint_as_float(braw[0].z); bv[3] = __uint_as_float(braw[0].w);
+    bv[4] = __uint_as_float(braw[1].x); bv[5] = __uint_as_float(braw[1].y); bv[6] = __uint_as_float(braw[1].z); bv[7] = __uint_as_float(braw[1].w);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+  }
   uint32_t cl = clane;
   asm volatile("" : "+v"(cl));
+  const uint32_t zl = cl;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     float v[8];
@@ -150,6 +158,9 @@ __device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * nt + j] = aq[mt][nt][j] + bv[4 * nt + j];
+    if constexpr (ZOUT)      // pre-activation side output for the backward (training)
+      *(uint4*)(ztile + (zl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * NH)) =
+          make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
     g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
@@ -385,13 +396,13 @@ __device__ __forceinline__ void g8p_stage(const __amdgpu_buffer_rsrc_t rs, char*
 }
 
 // The vmcnt queue is in order and also carries the epilogue stores and the bias DMA, so "all but the four youngest half-tiles
-// have landed" is a different count per iteration kind:
+// have landed" is a different count per iteration kind.  With QS = stores per quadrant and wave (4; 8 with the pre-activation
+// side output) and NB = 1 if a bias DMA sits in front of phase 0's stage of a tile's first iteration:
 //   G8P_STEADY  every wait 8
-//   G8P_ROLL    last iteration of a tile: 4 stores follow the stage of odd phases 1, 2, 3     -> odd waits 8, 8+4, 8+12
-//   G8P_HEAD    first iteration of the workgroup's first tile: the bias DMA sits in front of phase 0's stage
-//                                                                                             -> even waits 9, 9, 9
-//   G8P_HEAD    (pending) first iteration of a later tile: 12 stores + bias DMA + 4 stores (quadrant (1,0), after phase 0's stage)
-//                                                                                -> even waits 25, 25, 17; odd phase 0: 12
+//   G8P_ROLL    last iteration of a tile: QS stores follow the stage of odd phases 1, 2, 3    -> odd waits 8, 8 + QS, 8 + 3 QS
+//   G8P_HEAD    first iteration of the workgroup's first tile                                  -> even waits 8 + NB (x3)
+//   G8P_HEAD    (pending) first iteration of a later tile: 3 QS stores + bias DMA + QS stores (quadrant (1,0), after phase 0's
+//               stage) are younger than the awaited half-tile -> even waits 8 + NB + 4 QS (x2), 8 + NB + 2 QS; odd phase 0: 8 + QS
 // (derivation: count the operations younger than the half-tile the wait must retire)
 // The iteration kind is a template parameter (three copies of the loop body: head, steady, roll): selecting the count at run
 // time costs 3-5 scalar branches per wait, ~200 cycles per K tile (measured: -6.7 % at K = 4096).  Only the head copy, run once
@@ -408,48 +419,49 @@ __device__ __forceinline__ void g8p_wait(bool pending) {
 // Two K tiles.  p1 / p2 / p3 = panels of K tiles t+1, t+2, t+3 (t+2 and t+3 may already belong to the next output tile).
 // fin_c / fin_b = uniform output base and LDS bias address of the tile whose quadrants are written here: the current tile in a
 // G8P_ROLL iteration, the previous one in a pending G8P_HEAD (clane = this lane's offset inside an output tile).
-template <typename T, int ACT, int KIND>
+template <typename T, int ACT, bool BIAS, bool ZOUT, int KIND>
 __device__ __forceinline__ void g8p_iter(const GemmArgs& g, char* __restrict__ A0e, char* __restrict__ A1e, char* __restrict__ B0e,
                                          char* __restrict__ B1e, char* __restrict__ A0o, char* __restrict__ A1o,
                                          char* __restrict__ B0o, char* __restrict__ B1o, const __amdgpu_buffer_rsrc_t ra,
                                          const __amdgpu_buffer_rsrc_t rb, const G8Panel& p1, const G8Panel& p2,
                                          const G8Panel& p3, uint32_t HA, uint32_t HB, const uint32_t (&oa)[2], const uint32_t (&ob)[2],
                                          int wave_lds, const int (&xoff)[2], const int (&woff)[2][2], f32x4 (&acc)[2][2][4][2],
-                                         G8Frags<T>& f, bool pending, char* fin_c, uint32_t clane, uint32_t fin_b) {
+                                         G8Frags<T>& f, bool pending, char* fin_c, char* fin_z, uint32_t clane, uint32_t zlane, uint32_t fin_b) {
+  constexpr int QS = ZOUT ? 8 : 4, NB = BIAS ? 1 : 0;
   // ---- even tile ----
   g8_read_b(B0e, woff, f.b0); g8_read_a(A0e, xoff, f.a);
   g8p_stage(rb, B1o, p1.b + HB, ob, wave_lds);
-  if (KIND == G8P_HEAD && pending) g8p_fin_quadrant<T, ACT, 1, 0>(g, acc[1][0], fin_c, clane, fin_b);
-  g8p_wait<KIND, 8, 8, 9, 25>(pending);
+  if (KIND == G8P_HEAD && pending) g8p_fin_quadrant<T, ACT, BIAS, ZOUT, 1, 0>(g, acc[1][0], fin_c, fin_z, clane, zlane, fin_b);
+  g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 4 * QS>(pending);
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1e, woff, f.b1);
-  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<KIND, 8, 8, 9, 25>(pending);
+  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 4 * QS>(pending);
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1e, xoff, f.a);
   g8p_stage(ra, A0e, p2.a, oa, wave_lds);
   g8_mma<T>(acc[1][1], f.a, f.b1);
-  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<KIND, 8, 8, 9, 17>(pending);
+  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 2 * QS>(pending);
   g8_mma<T>(acc[1][0], f.a, f.b0);
   // ---- odd tile ----
   g8_read_b(B0o, woff, f.b0); g8_read_a(A0o, xoff, f.a);
-  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); g8p_wait<KIND, 8, 8, 8, 12>(pending);
+  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); g8p_wait<KIND, 8, 8, 8, 8 + QS>(pending);
   g8_mma<T>(acc[0][0], f.a, f.b0);
   g8_read_b(B1o, woff, f.b1);
   g8p_stage(ra, A1e, p2.a + HA, oa, wave_lds);
-  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 0, 0>(g, acc[0][0], fin_c, clane, fin_b);
-  g8p_wait<KIND, 8, 12, 8, 8>(pending);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, BIAS, ZOUT, 0, 0>(g, acc[0][0], fin_c, fin_z, clane, zlane, fin_b);
+  g8p_wait<KIND, 8, 8 + QS, 8, 8>(pending);
   g8_mma<T>(acc[0][1], f.a, f.b1);
   g8_read_a(A1o, xoff, f.a);
   g8p_stage(ra, A0o, p3.a, oa, wave_lds);
-  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 0, 1>(g, acc[0][1], fin_c, clane, fin_b);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, BIAS, ZOUT, 0, 1>(g, acc[0][1], fin_c, fin_z, clane, zlane, fin_b);
   g8_mma<T>(acc[1][1], f.a, f.b1);
   g8p_stage(rb, B0o, p3.b, ob, wave_lds);
-  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, 1, 1>(g, acc[1][1], fin_c, clane, fin_b);
-  g8p_wait<KIND, 8, 20, 8, 8>(pending);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant<T, ACT, BIAS, ZOUT, 1, 1>(g, acc[1][1], fin_c, fin_z, clane, zlane, fin_b);
+  g8p_wait<KIND, 8, 8 + 3 * QS, 8, 8>(pending);
   g8_mma<T>(acc[1][0], f.a, f.b0);
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool BIAS, bool ZOUT>
 __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -472,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   const uint32_t TA = 2 * HA, TB = 2 * HB;                                              // one tile row / column panel
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, g.N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? g.bias : (const float*)g.W), 0, g.N * 4, 0x00020000);
   const int wave_lds = wave * 1024;
   int xoff[2], woff[2][2];
 #pragma unroll
@@ -492,6 +504,7 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   const uint32_t bias_lane = (uint32_t)lane * 4u;
   const uint32_t bias_ad0 = lds_addr(bias_lds) + (uint32_t)(32 * wn + 8 * q) * 4u;
   const uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 2u;
+  const uint32_t zlane = clane;     // the side output has the row stride of the output (launcher: ldz == ldc); one VGPR fewer
 
   const int nkt = g.K >> 6;   // even, >= 4 (checked by the launcher)
   int bid = blockIdx.x, tm, tn;
@@ -517,6 +530,7 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   G8Frags<T> f;
   int parity = 0;
   char* prev_c = nullptr;                     // the tile whose quadrant (1,0) is still to be written: output base ...
+  char* prev_z = nullptr;                     // ... side-output base ...
   uint32_t prev_b = bias_ad0;                 // ... and LDS address of its bias
   for (;;) {
     const int nbid = bid + (int)gridDim.x;
@@ -527,34 +541,37 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
     const G8Panel nxt = has_next ? G8Panel{(uint32_t)ntm * TA, (uint32_t)ntn * TB}
                                  : G8Panel{cur.a + (uint32_t)(nkt - 2) * 128u, cur.b + (uint32_t)(nkt - 2) * 128u};
     char* const here_c = g.C + ((size_t)tm * 256 * g.ldc + (size_t)tn * 256) * 2;
+    char* const here_z = ZOUT ? g.zout + ((size_t)tm * 256 * g.ldc + (size_t)tn * 256) * 2 : nullptr;
     const uint32_t here_b = bias_ad0 + (uint32_t)parity * 1024u;
 
-#define G8P_ITER(KIND, P1, P2, P3, PEND, FC, FB) \
-  g8p_iter<T, ACT, KIND>(g, A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, P1, P2, P3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, PEND, FC, clane, FB)
+#define G8P_ITER(KIND, P1, P2, P3, PEND, FC, FZ, FB) \
+  g8p_iter<T, ACT, BIAS, ZOUT, KIND>(g, A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, P1, P2, P3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, PEND, FC, FZ, \
+                                     clane, zlane, FB)
     {  // head: K tiles 0, 1 (already staged); stages 1, 2, 3; the previous tile's quadrant (1,0) goes out in phase 0
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
-                                               (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
+      if constexpr (BIAS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
+                                                 (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
       const G8Panel p1 = {cur.a + 128u, cur.b + 128u}, p2 = {cur.a + 256u, cur.b + 256u}, p3 = {cur.a + 384u, cur.b + 384u};
-      G8P_ITER(G8P_HEAD, p1, p2, p3, prev_c != nullptr, prev_c, prev_b);
+      G8P_ITER(G8P_HEAD, p1, p2, p3, prev_c != nullptr, prev_c, prev_z, prev_b);
     }
     for (int t = 2; t + 2 < nkt; t += 2) {
       const G8Panel p1 = {cur.a + (uint32_t)(t + 1) * 128u, cur.b + (uint32_t)(t + 1) * 128u};
       const G8Panel p2 = {cur.a + (uint32_t)(t + 2) * 128u, cur.b + (uint32_t)(t + 2) * 128u};
       const G8Panel p3 = {cur.a + (uint32_t)(t + 3) * 128u, cur.b + (uint32_t)(t + 3) * 128u};
-      G8P_ITER(G8P_STEADY, p1, p2, p3, false, here_c, here_b);
+      G8P_ITER(G8P_STEADY, p1, p2, p3, false, here_c, here_z, here_b);
     }
     {  // roll: K tiles nkt-2, nkt-1; stages the next tile's K tiles 0 and 1; quadrants (0,0), (0,1), (1,1) of this tile go out
       const G8Panel p1 = {cur.a + (uint32_t)(nkt - 1) * 128u, cur.b + (uint32_t)(nkt - 1) * 128u};
       const G8Panel p3 = {nxt.a + 128u, nxt.b + 128u};
-      G8P_ITER(G8P_ROLL, p1, nxt, p3, false, here_c, here_b);
+      G8P_ITER(G8P_ROLL, p1, nxt, p3, false, here_c, here_z, here_b);
     }
 #undef G8P_ITER
-    prev_c = here_c; prev_b = here_b;
+    prev_c = here_c; prev_z = here_z; prev_b = here_b;
     if (!has_next) break;
     parity ^= 1;
     bid = nbid; tm = ntm; tn = ntn; cur = nxt;
   }
-  g8p_fin_quadrant<T, ACT, 1, 0>(g, acc[1][0], prev_c, clane, prev_b);   // last tile's last quadrant
+  g8p_fin_quadrant<T, ACT, BIAS, ZOUT, 1, 0>(g, acc[1][0], prev_c, prev_z, clane, zlane, prev_b);   // last tile's last quadrant
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail DMAs must land before exit
   if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
 }
@@ -575,9 +592,9 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, bool BIAS, bool ZOUT>
 static int g8p_launch(GemmArgs& g, hipStream_t stream) {
-  auto kern = gemm8p_kernel<T, ACT>;
+  auto kern = gemm8p_kernel<T, ACT, BIAS, ZOUT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT + 2048);
@@ -592,20 +609,32 @@ static int g8p_launch(GemmArgs& g, hipStream_t stream) {
 }
 
 // The persistent kernel takes problems made of whole 256x256 tiles (at least one per CU, at least two K iterations) with a
-// bias and a plain 16-bit output (qkv / out_proj / c_fc / c_proj of the encoders); everything else -- fp32 residual epilogue,
-// pre-activation side output, row remaps, no bias (dgrad) -- runs one tile per workgroup.
+// plain 16-bit output: the encoders' qkv / out_proj / c_fc / c_proj (bias), the same with the pre-activation side output of
+// training (QuickGELU c_fc), and the bias-free input-gradient GEMMs.  Everything else -- fp32 residual epilogue, row remaps,
+// other activation / side-output combinations -- runs one tile per workgroup.
 static bool g8p_eligible(const GemmArgs& g) {
   if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 256 || g.K < 256) return false;
   if ((size_t)g.M * g.lda * 2 >= (1ull << 31) || (size_t)g.N * g.ldw * 2 >= (1ull << 31)) return false;   // buffer descriptors / 32-bit offsets
-  if ((size_t)255 * g.ldc * 2 + 512 >= (1ull << 31)) return false;
-  return g.bias && !g.zout && g8_epi_kind(g) == G8_EPI_STORE16;
+  if ((size_t)255 * g.ldc * 2 + 512 >= (1ull << 31) || (g.zout && g.ldz != g.ldc)) return false;
+  return g8_epi_kind(g) == G8_EPI_STORE16;
 }
 
 template <typename T, int ACT>
 static int g8_pick(GemmArgs& g, hipStream_t s) {
-  // erf-GELU: hipcc spills four registers in the persistent kernel, and scratch accesses count in vmcnt -> one-tile kernel
-  if constexpr (ACT != VMC_ACT_GELU_ERF)
-    if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) return g8p_launch<T, ACT>(g, s);
+  // instantiated combinations only (each is a ~2000-instruction kernel); erf-GELU spills in the persistent kernel, and scratch
+  // accesses count in vmcnt -> one-tile kernel
+  if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) {
+    const bool b = g.bias != nullptr, z = g.zout != nullptr;
+    if constexpr (ACT == VMC_ACT_NONE) {
+      if (b && !z) return g8p_launch<T, ACT, true, false>(g, s);
+      if (!b && !z) return g8p_launch<T, ACT, false, false>(g, s);
+    } else if constexpr (ACT == VMC_ACT_QUICKGELU) {
+      if (b && !z) return g8p_launch<T, ACT, true, false>(g, s);
+      if (b && z) return g8p_launch<T, ACT, true, true>(g, s);
+    } else if constexpr (ACT == VMC_ACT_RELU) {
+      if (b && !z) return g8p_launch<T, ACT, true, false>(g, s);
+    }
+  }
   return g8_launch<T, ACT>(g, s);
 }
 
