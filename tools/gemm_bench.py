@@ -24,14 +24,19 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--act", type=int, default=0, help="0 none, 1 QuickGELU (adds a bias too)")
     ap.add_argument("--res32", action="store_true", help="fp32 residual in + fp32 out in place (out_proj / c_proj epilogue)")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (NOT a throughput figure: shows how much of the gap to "
+                    "peak is data-dependent power / clock, cdna_hip_programming.md rule 25)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     for s in args.shapes:
         M, N, K = map(int, s.split(","))
         a = torch.randn(M, K, device="cuda").to(dt)
         w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
+        if args.zeros:
+            a.zero_()
+            w.zero_()
         out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if args.res32 else dt)
-        bias = torch.randn(N, device="cuda") if (args.act or args.res32) else None
+        bias = torch.randn(N, device="cuda")          # every encoder linear has one (and the persistent kernel takes bias linears)
         kw = dict(bias=bias, out=out, act=args.act, res=out if args.res32 else None)
         res = {}
         for rnd in range(args.rounds):            # interleaved rounds in ONE process (variants share clocks/thermals)
