@@ -172,6 +172,13 @@ int vmc_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
  * ln_post (OpenAI clip ResidualAttentionBlock.forward).  D % 256 == 0, D <= 2048. */
 int vmc_add_layernorm_fwd(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows,
                           int D, int ldx, int ldb, float eps, int write_x, int dtype16, void* stream);
+
+/* The same with TWO 16-bit branches, x <- (x + branch0) + branch (in that order) and y16 = LN(x).  Lets the first add+LayerNorm of
+ * a pre-norm block (after out_proj; x = x + attention(...), modeling_clip.py / OpenAI clip ResidualAttentionBlock.forward) skip
+ * writing the fp32 stream back (write_x = 0) and the second one (after c_proj) redo that add from the kept attention branch:
+ * 22 instead of 24 bytes per element and layer, bit-identical stream. */
+int vmc_add2_layernorm_fwd(float* x, const void* branch0, const void* branch, const float* gamma, const float* beta, void* y16,
+                           int rows, int D, int ldx, int ldb0, int ldb, float eps, int write_x, int dtype16, void* stream);
 /* Post-norm block tail of the TFAM AttentionLayer (TFAM/models/AMO_CLIP.py:40,45,50: norm(x + dropout(branch))):
  * s = x (f32 [rows,D]) + branch (16-bit [rows,D]); y = LN(s) written as f32 (y32, next residual operand) and/or 16-bit
  * (y16, next GEMM operand); optional saves for the backward: sum_out = s, mean, rstd.  D % 256 == 0, D <= 2048. */

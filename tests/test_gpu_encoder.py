@@ -83,6 +83,23 @@ def test_last_block_on_class_rows_only_is_the_same_function(name):
         assert d <= (2e-4 if dtype == torch.float16 else 2e-3) * max(1.0, y_full.abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["tiny14", "b32", "l14"])
+def test_deferred_attention_add_is_bit_identical(name):
+    """vmc_add2_layernorm_fwd: the add+LayerNorm after out_proj does not write x + attention back, the one after c_proj redoes
+    (x + a) + m from the kept branch.  Same fp32 additions in the same order -> the embeddings must be EQUAL, also with the full-width
+    last block (whose ln_post path takes the strided class rows of both branches)."""
+    c = next(x for x in mg.VIT_CASES if x["name"] == name)
+    for dtype in (torch.float16, torch.bfloat16):
+        m = _encoder(c, dtype)
+        u8 = mg.vit_pixels(c).cuda()
+        for cls_only in (True, False):
+            m.cls_only_last_block = cls_only
+            m.defer_attn_add = True
+            y = m.encode_frames_u8(u8)
+            m.defer_attn_add = False
+            assert torch.equal(y, m.encode_frames_u8(u8)), (name, dtype, cls_only)
+
+
 def test_encoder_chunking_and_batch_independence():
     c = mg.VIT_CASES[0]
     m = _encoder(c, torch.bfloat16)

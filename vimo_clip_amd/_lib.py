@@ -42,6 +42,7 @@ SIGNATURES = {
     "vmc_colsum": (I, [P, P, I, I, I, I, P, Z, P]),
     "vmc_layernorm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),
     "vmc_add_layernorm_fwd": (I, [P, P, P, P, P, I, I, I, I, F, I, I, P]),
+    "vmc_add2_layernorm_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, I, P]),
     "vmc_postnorm_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, F, I, P]),
     "vmc_postnorm_dropout_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, F, F, ctypes.c_uint64, F, ctypes.c_uint64, I, P]),
     "vmc_layernorm_bwd_workspace_bytes": (Z, [I, I]),

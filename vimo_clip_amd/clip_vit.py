@@ -94,6 +94,10 @@ class VisionTransformer(nn.Module):
         self._w16 = {}          # name -> (param version, 16-bit copy)
         self.fuse_add_ln = True  # False: x += GEMM in the epilogue (fp32 read-modify-write), plain LayerNorm after it
         self.cls_only_last_block = True  # last block's out_proj / MLP on the F class rows only (what ln_post reads)
+        # x + attention branch not written back, the add+LN after c_proj redoes it (vmc_add2_layernorm_fwd: 22 instead of 24 B per
+        # element and layer, bit-identical).  Measured 41.04 vs 40.98 ms per step: the saved fp32 write is paid back by re-reading a
+        # branch that has left the caches -- off by default (profiles/README.md, round 2)
+        self.defer_attn_add = False
         self.exact_patch_embed = True   # split-precision patch GEMM (fp32-accurate; +0.2 % FLOPs): see patch_operands()
         self.frame_chunk = 256  # frames per pass (bounds activation memory; F*N*4D*2 B for the MLP buffer)
         self._init_weights()
@@ -214,9 +218,12 @@ class VisionTransformer(nn.Module):
                     cls, *_ = ops.layernorm(x, self.ln_post.weight, self.ln_post.bias, dt16, rows=F, ldx=N * D)
                 del u, o
                 break
+            defer = fused and trace is None and self.defer_attn_add
             if fused:
                 a = ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)
-                h = ops.add_layernorm_(x, a, blk.ln_2.weight, blk.ln_2.bias)
+                # defer: h = LN(x + a) without writing x + a back; the add+LayerNorm after c_proj redoes (x + a) + m from the
+                # kept attention branch -- 8 + 14 instead of 12 + 12 bytes per element, the same fp32 stream bit for bit
+                h = ops.add_layernorm_(x, a, blk.ln_2.weight, blk.ln_2.bias, write_x=not defer)
             else:
                 ops.linear(o, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias, res=x, out=x)
                 h, *_ = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, dt16)
@@ -226,11 +233,15 @@ class VisionTransformer(nn.Module):
             if fused:
                 m = ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias)
                 if last:       # only the class rows are needed after the last block: x[cls] + m[cls] -> ln_post
-                    cls = ops.add_layernorm_(x, m, self.ln_post.weight, self.ln_post.bias, rows=F, ldx=N * D, ldb=N * D, write_x=False)
+                    if defer:
+                        cls = ops.add_layernorm_(x, m, self.ln_post.weight, self.ln_post.bias, rows=F, ldx=N * D, ldb=N * D, write_x=False,
+                                                 branch0=a.view(F, N, D)[:, 0, :].contiguous())
+                    else:
+                        cls = ops.add_layernorm_(x, m, self.ln_post.weight, self.ln_post.bias, rows=F, ldx=N * D, ldb=N * D, write_x=False)
                 else:
                     nxt = blocks[i + 1]
-                    h = ops.add_layernorm_(x, m, nxt.ln_1.weight, nxt.ln_1.bias)
-                del m
+                    h = ops.add_layernorm_(x, m, nxt.ln_1.weight, nxt.ln_1.bias, branch0=a if defer else None)
+                del m, a
             else:
                 ops.linear(u, self.w16(pre + "c_proj", blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=x, out=x)
                 h = None

@@ -122,10 +122,10 @@ extern "C" int vmc_layernorm_fwd(const void* x, const float* gamma, const float*
 // the GEMM epilogues (where 2 x 256 KB per tile of fp32 traffic is serialised behind a 1-block-per-CU
 // main loop) and puts it in this HBM-streaming kernel instead.  CH = D / 256 chunks per lane, compile time.
 template <typename T, int CH>
-__global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, const uint16_t* __restrict__ branch,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     uint16_t* __restrict__ y16, int rows, size_t ldx, size_t ldb, float eps,
-                                                     int write_x) {
+__global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, const uint16_t* __restrict__ branch0,
+                                                     const uint16_t* __restrict__ branch, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, uint16_t* __restrict__ y16, int rows, size_t ldx,
+                                                     size_t ldb0, size_t ldb, float eps, int write_x) {
   constexpr int D = CH * 256;
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, cons
   }
   for (int row = wave_global; row < rows; row += nwaves) {
     float4 v[CH];
-    uint2 br[CH];
+    uint2 br[CH], br0[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       {   // streaming (non-temporal): x is next touched by the following add+LN, ~1 GB of GEMM traffic later; keeping it out
@@ -147,11 +147,17 @@ __global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, cons
         v[c] = make_float4(t[0], t[1], t[2], t[3]);
       }
       br[c] = *(const uint2*)(branch + (size_t)row * ldb + c * 256 + lane * 4);
+      if (branch0) br0[c] = *(const uint2*)(branch0 + (size_t)row * ldb0 + c * 256 + lane * 4);
     }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       float a0, a1, a2, a3;
+      if (branch0) {      // the add a previous pass skipped writing back: x = (x + branch0) + branch, in that order
+        unpack2<T>(br0[c].x, a0, a1);
+        unpack2<T>(br0[c].y, a2, a3);
+        v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
+      }
       unpack2<T>(br[c].x, a0, a1);
       unpack2<T>(br[c].y, a2, a3);
       v[c].x += a0; v[c].y += a1; v[c].z += a2; v[c].w += a3;
@@ -179,12 +185,12 @@ __global__ void __launch_bounds__(256) add_ln_kernel(float* __restrict__ x, cons
 }
 
 template <typename T>
-static int launch_add_ln(float* x, const void* branch, const float* gamma, const float* beta, void* y16, int rows, int D, size_t ldx,
-                         size_t ldb, float eps, int write_x, hipStream_t s) {
+static int launch_add_ln(float* x, const void* branch0, const void* branch, const float* gamma, const float* beta, void* y16, int rows,
+                         int D, size_t ldx, size_t ldb0, size_t ldb, float eps, int write_x, hipStream_t s) {
   const int grid = grid_for((size_t)rows, 4, 256 * 8);
 #define VMC_ADDLN(CHN)                                                                                                        \
-  hipLaunchKernelGGL((add_ln_kernel<T, CHN>), dim3(grid), dim3(256), 0, s, x, (const uint16_t*)branch, gamma, beta, (uint16_t*)y16, \
-                     rows, ldx, ldb, eps, write_x)
+  hipLaunchKernelGGL((add_ln_kernel<T, CHN>), dim3(grid), dim3(256), 0, s, x, (const uint16_t*)branch0, (const uint16_t*)branch, gamma, \
+                     beta, (uint16_t*)y16, rows, ldx, ldb0, ldb, eps, write_x)
   switch (D / 256) {
     case 1: VMC_ADDLN(1); break;
     case 2: VMC_ADDLN(2); break;
@@ -205,8 +211,20 @@ extern "C" int vmc_add_layernorm_fwd(float* x, const void* branch, const float* 
   if (!x || !branch || !gamma || !beta || !y16 || rows <= 0 || D <= 0) return VMC_E_ARG;
   if (D % 256 || D > 2048) return VMC_E_SHAPE;
   if (ldx % 4 || ldb % 4 || ldx < D || ldb < D) return VMC_E_ALIGN;
-  if (dtype16 == VMC_BF16) return launch_add_ln<BF16>(x, branch, gamma, beta, y16, rows, D, ldx, ldb, eps, write_x, (hipStream_t)stream);
-  if (dtype16 == VMC_F16) return launch_add_ln<F16>(x, branch, gamma, beta, y16, rows, D, ldx, ldb, eps, write_x, (hipStream_t)stream);
+  if (dtype16 == VMC_BF16) return launch_add_ln<BF16>(x, nullptr, branch, gamma, beta, y16, rows, D, ldx, 0, ldb, eps, write_x, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return launch_add_ln<F16>(x, nullptr, branch, gamma, beta, y16, rows, D, ldx, 0, ldb, eps, write_x, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_add2_layernorm_fwd(float* x, const void* branch0, const void* branch, const float* gamma, const float* beta, void* y16,
+                                      int rows, int D, int ldx, int ldb0, int ldb, float eps, int write_x, int dtype16, void* stream) {
+  if (!x || !branch0 || !branch || !gamma || !beta || !y16 || rows <= 0 || D <= 0) return VMC_E_ARG;
+  if (D % 256 || D > 2048) return VMC_E_SHAPE;
+  if (ldx % 4 || ldb0 % 4 || ldb % 4 || ldx < D || ldb0 < D || ldb < D) return VMC_E_ALIGN;
+  if (dtype16 == VMC_BF16)
+    return launch_add_ln<BF16>(x, branch0, branch, gamma, beta, y16, rows, D, ldx, ldb0, ldb, eps, write_x, (hipStream_t)stream);
+  if (dtype16 == VMC_F16)
+    return launch_add_ln<F16>(x, branch0, branch, gamma, beta, y16, rows, D, ldx, ldb0, ldb, eps, write_x, (hipStream_t)stream);
   return VMC_E_DTYPE;
 }
 

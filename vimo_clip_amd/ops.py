@@ -143,11 +143,17 @@ def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False,
 
 
 def add_layernorm_(x32: torch.Tensor, branch16: torch.Tensor, gamma, beta, *, rows=None, ldx=None, ldb=None, write_x=True,
-                   eps: float = 1e-5) -> torch.Tensor:
-    """x32 += branch16 (in place, fp32 residual stream) and return LN(x32) in branch16's dtype (vmc_add_layernorm_fwd)."""
+                   eps: float = 1e-5, branch0=None) -> torch.Tensor:
+    """x32 += branch16 (in place, fp32 residual stream) and return LN(x32) in branch16's dtype (vmc_add_layernorm_fwd).
+    branch0: a second 16-bit branch added FIRST, x32 = (x32 + branch0) + branch16 (vmc_add2_layernorm_fwd): the add an earlier
+    call with write_x=False left out of the stored stream."""
     D = gamma.shape[0]
     rows = x32.numel() // D if rows is None else rows
     y = torch.empty((rows, D), dtype=branch16.dtype, device=x32.device)
+    if branch0 is not None:
+        check(lib.vmc_add2_layernorm_fwd(ptr(x32), ptr(branch0), ptr(branch16), ptr(gamma), ptr(beta), ptr(y), rows, D, ldx or D, D, ldb or D,
+                                         float(eps), int(write_x), dt(branch16), stream()), "add2_layernorm_fwd")
+        return y
     check(lib.vmc_add_layernorm_fwd(ptr(x32), ptr(branch16), ptr(gamma), ptr(beta), ptr(y), rows, D, ldx or D, ldb or D, float(eps),
                                     int(write_x), dt(branch16), stream()), "add_layernorm_fwd")
     return y
