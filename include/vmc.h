@@ -150,6 +150,12 @@ int vmc_transpose16(const void* in, void* out, int rows, int cols, int ld_in, in
 int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows, int cols, int ld_out, int ld_out_t,
                     int dtype16, void* stream);
 
+/* The same for many weights in ONE launch: after an optimiser step (`optimizer.step()`, train.py:107, TFAM/train_and_eval.py:96)
+ * every 16-bit compute copy of the trained parameters is refreshed in place.  `desc` is a DEVICE array of n_desc records of
+ * 48 bytes {const float* w; void* w16; void* w16_t; int rows, cols, ld_out, ld_out_t, tile0, tiles_x;} (NULL copies are skipped);
+ * record i owns the 64x64 tiles [tile0, tile0 of record i+1) of a 1-D grid of total_tiles, tiles_x = ceil(cols / 64). */
+int vmc_cast_weights_multi(const void* desc, int n_desc, int total_tiles, int dtype16, void* stream);
+
 /* Column sums  out[n] = sum_m in[m, n]  (bias gradients, K8).  N % 4 == 0, ld_in % 4 == 0.  workspace: >= vmc_colsum_workspace_bytes. */
 size_t vmc_colsum_workspace_bytes(int M, int N);
 int vmc_colsum(const void* in, float* out, int M, int N, int ld_in, int in_dtype, void* workspace,

@@ -314,3 +314,35 @@ def test_linear_preact_side_output(ops, M, N, K, act):
     z = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
     y = ops.linear(a, w, bias=bias, act=act, z_out=z)
     assert torch.equal(z, z_ref) and torch.equal(y, y_ref)
+
+
+def test_cast_weights_multi_refresh_matches_single_casts(ops):
+    """vmc_cast_weights_multi (all cached 16-bit copies of the trained parameters re-cast in place after an optimiser step) ==
+    vmc_cast_weight per parameter, for aligned and unaligned masters, ragged shapes (vector and scalar paths), padded copies."""
+    from vimo_clip_amd import autograd_ops as ag
+    ag.weights.clear()
+    flat = torch.randn(4 * 1024 * 1024, device=DEV)
+    shapes = [(768, 768), (2304, 768), (140, 768), (768, 140), (77, 130), (64, 3), (1000, 36)]
+    params, off = [], 0
+    for i, (r, c) in enumerate(shapes):
+        off += (i % 2)                               # every other master starts at an odd float offset (unaligned)
+        params.append(torch.nn.Parameter(flat[off:off + r * c].view(r, c)))
+        off += r * c
+
+    def copies(dtype, p):
+        r, c = p.shape
+        return (ag.weights.get(p, dtype, pad_k=(c % 64 != 0), both=True), ag.weights.get(p, dtype, transposed=True, pad_k=(r % 64 != 0)))
+
+    before = {(dtype, i): copies(dtype, p) for dtype in DT16 for i, p in enumerate(params)}
+    # rewrite the masters the way the optimiser kernels do: through the raw storage, behind autograd's version counters
+    flat.untyped_storage().copy_(torch.randn_like(flat).untyped_storage())
+    epoch = ag.weights.epoch
+    ag.weights.refresh()
+    assert ag.weights.epoch == epoch + 1
+    for dtype in DT16:
+        for i, p in enumerate(params):
+            w, wt = copies(dtype, p)
+            assert w.data_ptr() == before[(dtype, i)][0].data_ptr() and wt.data_ptr() == before[(dtype, i)][1].data_ptr()   # refreshed in place
+            ref, ref_t = ops.cast_weight_both(p, dtype)
+            assert torch.equal(w, ref) and torch.equal(wt, ref_t), (dtype, tuple(p.shape))
+    ag.weights.clear()

@@ -38,6 +38,7 @@ SIGNATURES = {
     "vmc_linear_variant": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, P]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),
+    "vmc_cast_weights_multi": (I, [P, I, I, I, P]),
     "vmc_colsum_workspace_bytes": (Z, [I, I]),
     "vmc_colsum": (I, [P, P, I, I, I, I, P, Z, P]),
     "vmc_layernorm_fwd": (I, [P, P, P, P, P, P, P, I, I, I, F, I, I, P]),

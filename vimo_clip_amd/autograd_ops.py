@@ -28,6 +28,8 @@ ACT_NONE = ops.ACT_NONE
 class _WeightCache:
     def __init__(self):
         self._c = {}
+        self._tables = {}       # dtype16 -> (key, device descriptor table, n, tiles) of refresh()
+        self._old_tables = []
         self.epoch = 0          # bumped whenever the masters may have changed behind autograd's version counters
 
     def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False, both=False):
@@ -52,6 +54,49 @@ class _WeightCache:
 
     def clear(self):
         self._c.clear()
+        self._tables.clear()
+        self.epoch += 1
+
+    def refresh(self):
+        """The optimiser kernel rewrote the fp32 masters in place: re-cast every cached copy of the trained parameters into its
+        existing buffer with ONE launch per compute dtype (vmc_cast_weights_multi) instead of dropping the copies and re-casting
+        them one launch per parameter in the next forward.  Buffers keep their addresses (what a captured step needs)."""
+        import numpy as np
+        groups = {}                                   # dtype16 -> {id(p): [p, w16, w16t]}
+        for (pid, dtype16, transposed, _pad), hit in list(self._c.items()):
+            p = hit[0]()
+            if p is None or hit[2] != p.data_ptr() or hit[1] != p._version or not p.requires_grad:
+                if p is None or hit[2] != p.data_ptr() or hit[1] != p._version:
+                    del self._c[(pid, dtype16, transposed, _pad)]      # stale: the next get() re-casts
+                continue                              # frozen parameters keep their copies as they are
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                del self._c[(pid, dtype16, transposed, _pad)]
+                continue
+            slot = groups.setdefault(dtype16, {}).setdefault(pid, [p, None, None])
+            slot[2 if transposed else 1] = hit[3]
+        for dtype16, params in groups.items():
+            key = (dtype16, tuple((pid, 0 if w is None else w.data_ptr(), 0 if wt is None else wt.data_ptr(), p.data_ptr())
+                                  for pid, (p, w, wt) in params.items()))
+            tab = self._tables.get(dtype16)
+            if tab is None or tab[0] != key:
+                rec = np.zeros((len(params), 6), dtype=np.int64)
+                tile0 = 0
+                for i, (p, w, wt) in enumerate(params.values()):
+                    rows = p.shape[0]
+                    cols = p.numel() // rows
+                    tx, ty = (cols + 63) // 64, (rows + 63) // 64
+                    rec[i, 0] = p.data_ptr()
+                    rec[i, 1] = 0 if w is None else w.data_ptr()
+                    rec[i, 2] = 0 if wt is None else wt.data_ptr()
+                    rec[i, 3] = rows | (cols << 32)
+                    rec[i, 4] = (0 if w is None else w.stride(0)) | ((0 if wt is None else wt.stride(0)) << 32)
+                    rec[i, 5] = tile0 | (tx << 32)
+                    tile0 += tx * ty
+                dev = next(iter(params.values()))[0].device
+                tab = (key, torch.from_numpy(rec).to(dev), len(params), tile0)
+                self._tables[dtype16] = tab
+                self._old_tables.append(tab[1])       # a captured graph may still read an older table
+            check(lib.vmc_cast_weights_multi(ptr(tab[1]), tab[2], tab[3], dt(dtype16), stream()), "cast_weights_multi")
         self.epoch += 1
 
 

@@ -358,6 +358,86 @@ extern "C" int vmc_cast_weight(const float* w, void* w16, void* w16_t, int rows,
   return 0;
 }
 
+// ---- the same for MANY weights in one launch (after an optimiser step: every cached compute copy of the trained parameters) ----
+// desc[i] = {w, w16, w16t, rows, cols, ld, ldt, tile0, tiles_x}: tensor i owns tiles [tile0, tile0 of i+1) of the 1-D grid.
+struct CastDesc {
+  const float* w;
+  uint16_t* w16;
+  uint16_t* w16t;
+  int rows, cols, ld, ldt, tile0, tiles_x;
+};
+static_assert(sizeof(CastDesc) == 48, "vmc_cast_weights_multi descriptor layout (include/vmc.h)");
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_weights_multi_kernel(const CastDesc* __restrict__ desc, int n) {
+  __shared__ uint16_t tile[64][68];             // 136-B rows: 8-byte aligned row starts for the 4-element writes
+  int lo = 0, hi = n - 1;                       // last descriptor whose tile0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int t = blockIdx.x - d.tile0;
+  const int r0 = (t / d.tiles_x) * 64, c0 = (t % d.tiles_x) * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 elements each per pass, 4 passes
+  // vector path: 16-byte loads of the master, 8-byte stores of both copies (all of a tensor's rows / strides must allow it)
+  const bool vec = (((uintptr_t)d.w & 15) == 0) && (d.cols & 3) == 0 && (d.rows & 3) == 0 && (!d.w16 || ((d.ld & 3) == 0 && ((uintptr_t)d.w16 & 7) == 0)) &&
+                   (!d.w16t || ((d.ldt & 3) == 0 && ((uintptr_t)d.w16t & 7) == 0));
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+      uint2 pk = make_uint2(0u, 0u);
+      if (r < d.rows && c < d.cols) {
+        const float4 v = *(const float4*)(d.w + (size_t)r * d.cols + c);
+        pk = make_uint2((uint32_t)T::from_f32(v.x) | ((uint32_t)T::from_f32(v.y) << 16), (uint32_t)T::from_f32(v.z) | ((uint32_t)T::from_f32(v.w) << 16));
+        if (d.w16) *(uint2*)(d.w16 + (size_t)r * d.ld + c) = pk;
+      }
+      *(uint2*)&tile[ty + 16 * i][4 * tx] = pk;
+    }
+    if (!d.w16t) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 16 * i, r = r0 + 4 * tx;          // output row c of the transposed copy, 4 consecutive r
+      if (c < d.cols && r < d.rows) {
+        const int cl = ty + 16 * i;
+        *(uint2*)(d.w16t + (size_t)c * d.ldt + r) = make_uint2((uint32_t)tile[4 * tx][cl] | ((uint32_t)tile[4 * tx + 1][cl] << 16),
+                                                              (uint32_t)tile[4 * tx + 2][cl] | ((uint32_t)tile[4 * tx + 3][cl] << 16));
+      }
+    }
+    return;
+  }
+  const int sx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  for (int i = sy; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + sx;
+    uint16_t v = 0;
+    if (r < d.rows && c < d.cols) {
+      v = T::from_f32(d.w[(size_t)r * d.cols + c]);
+      if (d.w16) d.w16[(size_t)r * d.ld + c] = v;
+    }
+    tile[i][sx] = v;
+  }
+  if (!d.w16t) return;
+  __syncthreads();
+  for (int i = sy; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + sx;
+    if (c < d.cols && r < d.rows) d.w16t[(size_t)c * d.ldt + r] = tile[sx][i];
+  }
+}
+
+extern "C" int vmc_cast_weights_multi(const void* desc, int n_desc, int total_tiles, int dtype16, void* stream) {
+  if (!desc || n_desc <= 0 || total_tiles <= 0) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(cast_weights_multi_kernel<BF16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)desc, n_desc);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(cast_weights_multi_kernel<F16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)desc, n_desc);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- column sums (bias gradients): partials per row-slab, then a reduce ---------------------------
 #define COLSUM_SLABS 256
 // partial[slab, n] = sum of rows [slab*rp, (slab+1)*rp): 64 lanes x 4 columns (8-/16-byte loads) across, 4 row

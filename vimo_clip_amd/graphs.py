@@ -63,6 +63,8 @@ class GraphedTrainStep:
         for t, s in zip(live, saved):
             t.copy_(s)
         o.step_count = count
+        from . import autograd_ops
+        autograd_ops.weights.refresh()          # the 16-bit compute copies follow the restored masters
         return g
 
     def __call__(self, *inputs):

@@ -146,10 +146,10 @@ class FusedAdam:
 
 
 def invalidate_weight_copies():
-    """The optimiser kernel wrote the fp32 masters behind autograd's version counters: drop the cached
-    16-bit compute copies so the next forward re-casts them."""
+    """The optimiser kernel wrote the fp32 masters behind autograd's version counters: the cached 16-bit compute copies of
+    the trained parameters are re-cast into their buffers in one launch (autograd_ops._WeightCache.refresh)."""
     from . import autograd_ops
-    autograd_ops.weights.clear()
+    autograd_ops.weights.refresh()
 
 
 class CosineAnnealingLR:
