@@ -68,16 +68,32 @@ def spawn_ranks(n: int, argv) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                                 # exact PID of a child this process started
-            p.wait()
-        rc = rc or p.returncode
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = list(procs)
+    while live:                                      # a rank that dies must not leave the others waiting in a rendezvous
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 20          # the rest get a moment to fail by themselves, then are ended
+                while live and time.time() < deadline:
+                    live = [q for q in live if q.poll() is None]
+                    time.sleep(0.2)
+                for q in live:
+                    q.kill()                         # exact PIDs of children this process started
+                for q in live:
+                    q.wait()
+                live = []
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
     sys.stdout.write(out0 or "")
     sys.stdout.flush()
     return int(rc != 0)
@@ -390,6 +406,8 @@ def selftest_spawn(rank: int, world: int) -> None:
     """CPU rehearsal of the N-rank control flow (tests/test_bench_spawn.py): gloo rendezvous from the spawned environment,
     one all-reduce, rank 0 prints a line in the bench format.  No GPU is touched."""
     import torch.distributed as dist
+    if os.environ.get("VMC_SELFTEST_DIE_EARLY_RANK") == str(rank):
+        sys.exit(3)                                  # dies before the rendezvous: the other ranks would wait for it
     if world > 1:
         dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)])

@@ -38,6 +38,16 @@ def test_failing_rank_fails_the_job():
     assert r.returncode != 0
 
 
+def test_rank_that_dies_before_the_rendezvous_ends_the_job_promptly():
+    """A rank that exits before init_process_group (e.g. its device does not exist) leaves the others blocked in the rendezvous:
+    the parent must end them (exact child PIDs) and fail, not wait for the collective time-out."""
+    import time
+    t0 = time.time()
+    r = _run(2, {"VMC_SELFTEST_DIE_EARLY_RANK": "1"})
+    assert r.returncode != 0
+    assert time.time() - t0 < 90
+
+
 def test_single_rank_needs_no_spawn():
     r = _run(1)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
