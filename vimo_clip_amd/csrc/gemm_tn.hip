@@ -5,7 +5,8 @@
 // pipeline stage.  A stage holds three [64 tokens][128 columns] sub-tiles (256-B rows of sixteen 16-B chunks): dY
 // columns 0..127, dY columns 128..255, X columns 0..127.  They are filled by global_load_lds_dwordx4 (lane-linear
 // LDS image; the XOR swizzle of the chunk slot by the token row is applied on the SOURCE address) into a 3-stage ring
-// (144 KiB), two stages in flight ahead of the MFMAs, counted vmcnt.  Both MFMA operands are fetched with
+// (144 KiB), two stages in flight ahead of the MFMAs, counted vmcnt; the two waves of a SIMD run one barrier apart (ping-pong, as
+// gemm8.hip: one issues its MFMA cluster while the other issues its transposed reads and the DMA; student step 22.2 -> 21.9 ms).  Both MFMA operands are fetched with
 // ds_read_b64_tr_b16: lane (c = lane & 15, g = lane >> 4) receives tokens 8g..8g+7 of column c, the k-slots of
 // v_mfma_f32_16x16x32.  With the swizzle slot = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)) the 32 lanes of one
 // transposed read touch 32 distinct 8-byte units of 64 banks (conflict free).
@@ -99,14 +100,22 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
   for (int a = 0; a < 4; ++a) bacc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (s0 < s1) {
+    // Ping-pong form of the stage loop (the schedule of gemm8.hip): waves w and w + 4 share a SIMD; the upper four run one
+    // s_barrier behind the lower four, so while one wave of a SIMD issues its 16 (+4) MFMAs its partner issues the transposed
+    // reads of its next 32 tokens and the stage DMA.  Two phases per 64-token stage:
+    //   phase (st, ks): 16 ds_read_b64_tr of tokens 32 ks.. | ks = 0: DMA of stage st + 2, ks = 1: wait for stage st + 1 |
+    //                   lgkmcnt(0) | barrier | MFMAs | barrier
+    // lgkmcnt(0) sits in FRONT of the first barrier: every wave's reads of a ring slot have completed when any wave passes it,
+    // so the slot of stage st - 1 (last read in phase (st-1, 1)) may be restaged one phase later, in phase (st, 0).  A stage is
+    // waited for (counted vmcnt, each wave for its own DMA) in the phase before its first read; the barriers publish it.
+    const int grp = wave >> 2;
     stage_in(s0);
     if (s0 + 1 < s1) stage_in(s0 + 1);
+    if (s0 + 1 < s1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger
     for (int st = s0; st < s1; ++st) {
-      if (st + 1 < s1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // stage st landed for every wave; everyone is done reading stage st-1
-      __builtin_amdgcn_sched_barrier(0);     // (raw barrier: __syncthreads would drain the DMAs still in flight)
-      if (st + 2 < s1) stage_in(st + 2);     // into the ring slot of stage st-1
       char* cur = smem + (st % TN_STAGES) * TN_STAGE;
       if (st * 64 + 64 > M) {                // tail stage: token rows past M become zeros in all three sub-tiles
         const int valid = M - st * 64;
@@ -118,54 +127,47 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(const uint16_t* __restrict
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();        // two, so that both groups see the zeros before either reads (they run one apart)
       }
       __builtin_amdgcn_sched_barrier(0);
       const uint32_t base = tn_lds_addr(cur);
-      uint2 af[2][4][2], bf[2][4][2];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int ks = 0; ks < 2; ++ks) {
+        uint2 af[4][2], bf[4][2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          tn_read_tr<0>(af[0][t][e], base + aoff[t][e]);
-          tn_read_tr<0>(bf[0][t][e], base + boff[t][e]);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (ks == 0) { tn_read_tr<0>(af[t][e], base + aoff[t][e]); tn_read_tr<0>(bf[t][e], base + boff[t][e]); }
+            else { tn_read_tr<8192>(af[t][e], base + aoff[t][e]); tn_read_tr<8192>(bf[t][e], base + boff[t][e]); }
+          }
+        if (ks == 0) {
+          if (st + 2 < s1) stage_in(st + 2);                 // into the ring slot of stage st - 1
+        } else if (st + 1 < s1) {                            // stage st + 1 (issued in phase (st-1, 0)) must have landed
+          if (st + 2 < s1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)                 // second 32 tokens: in flight under the first 16 MFMAs
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          tn_read_tr<8192>(af[1][t][e], base + aoff[t][e]);
-          tn_read_tr<8192>(bf[1][t][e], base + boff[t][e]);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = T::mfma16(make_uint4(af[0][a][0].x, af[0][a][0].y, af[0][a][1].x, af[0][a][1].y),
-                                make_uint4(bf[0][b][0].x, bf[0][b][0].y, bf[0][b][1].x, bf[0][b][1].y), acc[a][b]);
-      if (do_bias) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-          bacc[a] = T::mfma16(make_uint4(af[0][a][0].x, af[0][a][0].y, af[0][a][1].x, af[0][a][1].y), ones, bacc[a]);
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = T::mfma16(make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y),
+                                  make_uint4(bf[b][0].x, bf[b][0].y, bf[b][1].x, bf[b][1].y), acc[a][b]);
+        if (do_bias) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) bacc[a] = T::mfma16(make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y), ones, bacc[a]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
       }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = T::mfma16(make_uint4(af[1][a][0].x, af[1][a][0].y, af[1][a][1].x, af[1][a][1].y),
-                                make_uint4(bf[1][b][0].x, bf[1][b][0].y, bf[1][b][1].x, bf[1][b][1].y), acc[a][b]);
-      if (do_bias) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          bacc[a] = T::mfma16(make_uint4(af[1][a][0].x, af[1][a][0].y, af[1][a][1].x, af[1][a][1].y), ones, bacc[a]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
   }
   // lane holds C[n = n0 + 64 wn + 16 a + 4 g + j][k = k0 + 64 wk + 16 b + r]
   float* out = C + (size_t)blockIdx.y * N * K;
