@@ -79,6 +79,9 @@ class _WeightCache:
                                   for pid, (p, w, wt) in params.items()))
             tab = self._tables.get(dtype16)
             if tab is None or tab[0] != key:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("weight-copy table changed while a graph is being captured: run one eager step first "
+                                       "(GraphedTrainStep's warm-up does) so that every compute copy exists before the capture")
                 rec = np.zeros((len(params), 6), dtype=np.int64)
                 tile0 = 0
                 for i, (p, w, wt) in enumerate(params.values()):
