@@ -333,7 +333,7 @@ def tfam_extras(dev, rank, world, cdt):
     # AdamW kernel alone: HIP events on the launch stream, HBM roofline (16 B read + 12 B write per parameter)
     from vimo_clip_amd import optim as _optim
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    refresh, _optim.invalidate_weight_copies = _optim.invalidate_weight_copies, (lambda: None)   # the AdamW kernel alone, without
+    refresh, _optim.invalidate_weight_copies = _optim.invalidate_weight_copies, (lambda *a: None)   # the AdamW kernel alone, without
     try:                                                                                         # the 16-bit copy refresh after it
         opt.step()
         torch.cuda.synchronize()
@@ -344,7 +344,7 @@ def tfam_extras(dev, rank, world, cdt):
         torch.cuda.synchronize()
     finally:
         _optim.invalidate_weight_copies = refresh
-    refresh()
+    refresh(opt)
     t_adam = e0.elapsed_time(e1) * 1e-3 / 20
     bytes_adam = arena.numel * 28.0
     out["adamw_roofline"] = {"bound": "hbm", "achieved": round(bytes_adam / t_adam / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

@@ -57,13 +57,17 @@ class _WeightCache:
         self._tables.clear()
         self.epoch += 1
 
-    def refresh(self):
+    def refresh(self, owner=None, param_ids=None):
         """The optimiser kernel rewrote the fp32 masters in place: re-cast every cached copy of the trained parameters into its
         existing buffer with ONE launch per compute dtype (vmc_cast_weights_multi) instead of dropping the copies and re-casting
-        them one launch per parameter in the next forward.  Buffers keep their addresses (what a captured step needs)."""
+        them one launch per parameter in the next forward.  Buffers keep their addresses (what a captured step needs).
+        param_ids: ids of the parameters that were updated (an optimiser's arena); None = every cached trained parameter.
+        owner: key under which the descriptor table of that parameter set is kept (the optimiser)."""
         import numpy as np
         groups = {}                                   # dtype16 -> {id(p): [p, w16, w16t]}
         for (pid, dtype16, transposed, _pad), hit in list(self._c.items()):
+            if param_ids is not None and pid not in param_ids:
+                continue                              # another model's parameters: untouched by this step, copies stay valid
             p = hit[0]()
             if p is None or hit[2] != p.data_ptr() or hit[1] != p._version or not p.requires_grad:
                 if p is None or hit[2] != p.data_ptr() or hit[1] != p._version:
@@ -77,7 +81,7 @@ class _WeightCache:
         for dtype16, params in groups.items():
             key = (dtype16, tuple((pid, 0 if w is None else w.data_ptr(), 0 if wt is None else wt.data_ptr(), p.data_ptr())
                                   for pid, (p, w, wt) in params.items()))
-            tab = self._tables.get(dtype16)
+            tab = self._tables.get((owner, dtype16))
             if tab is None or tab[0] != key:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("weight-copy table changed while a graph is being captured: run one eager step first "
@@ -97,7 +101,7 @@ class _WeightCache:
                     tile0 += tx * ty
                 dev = next(iter(params.values()))[0].device
                 tab = (key, torch.from_numpy(rec).to(dev), len(params), tile0)
-                self._tables[dtype16] = tab
+                self._tables[(owner, dtype16)] = tab
                 self._old_tables.append(tab[1])       # a captured graph may still read an older table
             check(lib.vmc_cast_weights_multi(ptr(tab[1]), tab[2], tab[3], dt(dtype16), stream()), "cast_weights_multi")
         self.epoch += 1

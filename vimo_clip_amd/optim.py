@@ -124,7 +124,7 @@ class FusedAdam:
             check(lib.vmc_adam_step_dev(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, ptr(self.dev_hyper),
                                         float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                         int(self.decoupled), stream()), "adam_step_dev")
-            invalidate_weight_copies()
+            invalidate_weight_copies(self)
             return
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
             grad_scale = clipped_grad_scale(float(a.grad_norm().item()), grad_scale, max_grad_norm)
@@ -133,7 +133,7 @@ class FusedAdam:
         check(lib.vmc_adam_step(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, float(lr),
                                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                                 int(self.decoupled), self.step_count, float(grad_scale), stream()), "adam_step")
-        invalidate_weight_copies()
+        invalidate_weight_copies(self)
 
     def state_dict(self):
         return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
@@ -145,11 +145,17 @@ class FusedAdam:
         self.param_groups[0]["lr"] = sd["lr"]
 
 
-def invalidate_weight_copies():
+def invalidate_weight_copies(optimizer=None):
     """The optimiser kernel wrote the fp32 masters behind autograd's version counters: the cached 16-bit compute copies of
-    the trained parameters are re-cast into their buffers in one launch (autograd_ops._WeightCache.refresh)."""
+    the parameters it owns are re-cast into their buffers in one launch (autograd_ops._WeightCache.refresh)."""
     from . import autograd_ops
-    autograd_ops.weights.refresh()
+    if optimizer is None:
+        autograd_ops.weights.refresh()
+        return
+    ids = getattr(optimizer, "_param_ids", None)
+    if ids is None:
+        ids = optimizer._param_ids = frozenset(id(p) for p in optimizer.arena.params)
+    autograd_ops.weights.refresh(owner=id(optimizer), param_ids=ids)
 
 
 class CosineAnnealingLR:
