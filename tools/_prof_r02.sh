@@ -21,5 +21,11 @@ timeout -k 10 300 python3 tools/gemm_persist_check.py --repeats 5 > $O/gemm_pers
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tf -- python3 tools/tfam_chain_run.py 8 100 > $O/tf.log 2>&1
 find $O/tf -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/tfam_chain_B8_kernel_stats.csv
 rm -rf $O/tf
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 tools/student_bench.py > $O/st.log 2>&1
+find $O/st -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/student_train_kernel_stats.csv
+rm -rf $O/st
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tc -- python3 tools/tfam_train_census.py 8 20 > $O/tc.log 2>&1
+find $O/tc -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/tfam_train_B8_census_kernel_stats.csv
+rm -rf $O/tc
 tail -c 400 $O/bench_line.json
 cat $O/gemm8_pmc.txt
