@@ -217,6 +217,12 @@ int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int F, int N, int H, int dtype16,
                           void* stream);
 
+/* The same attention for the CLASS-TOKEN query only: what the last residual block of the encoder needs (only x[:, 0] reaches
+ * ln_post: `x = self.ln_post(x[:, 0, :])`, OpenAI clip model.py; modeling_clip.py:650 pooled_output = last_hidden_state[:, 0]).
+ *   q_cls 16-bit [F, D] (the class rows' queries), kv 16-bit [F*N, 2*D] (columns [0,D)=K, [D,2D)=V of every token),
+ *   out 16-bit [F, D].  Same kernel, one 16-row query tile per (frame, head) instead of ceil(N/16). */
+int vmc_attention_vit_cls_fwd(const void* q_cls, const void* kv, void* out, int F, int N, int H, int dtype16, void* stream);
+
 /* K4/K11/K12 generic masked attention (fp32 math), any head_dim <= 128 with head_dim % 8 == 0.
  * Replaces F.multi_head_attention_forward's core (q*dh^-1/2, key_padding_mask -> -inf, softmax, @V)
  * for the TFAM self/cross attention (TFAM/models/AMO_CLIP.py:39-45) and serves as the backward's

@@ -100,6 +100,24 @@ def test_deferred_attention_add_is_bit_identical(name):
             assert torch.equal(y, m.encode_frames_u8(u8)), (name, dtype, cls_only)
 
 
+@pytest.mark.parametrize("name", ["tiny14", "b32", "l14"])
+def test_class_query_attention_in_the_last_block_is_the_same_function(name):
+    """vmc_attention_vit_cls_fwd: the last block computes K | V for every token but the query (and the attention rows) of the class
+    token only.  A query row's attention does not depend on the other query rows, so the embeddings must equal the full last-block
+    attention bit for bit (the q projection of the class rows runs on a small-tile GEMM: same k order)."""
+    c = next(x for x in mg.VIT_CASES if x["name"] == name)
+    for dtype in (torch.float16, torch.bfloat16):
+        m = _encoder(c, dtype)
+        u8 = mg.vit_pixels(c).cuda()
+        assert m.cls_query_last_block and m.cls_only_last_block
+        y = m.encode_frames_u8(u8)
+        m.cls_query_last_block = False
+        y_full = m.encode_frames_u8(u8)
+        d = (y - y_full).abs().max().item()
+        print(f"{name} {dtype}: class-query attention vs full attention in the last block: max abs diff {d:.2e}")
+        assert d <= 1e-6 * max(1.0, y_full.abs().max().item())
+
+
 def test_encoder_chunking_and_batch_independence():
     c = mg.VIT_CASES[0]
     m = _encoder(c, torch.bfloat16)

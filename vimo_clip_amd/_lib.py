@@ -54,6 +54,7 @@ SIGNATURES = {
     "vmc_assemble_tokens": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vmc_dropout": (I, [P, P, Z, F, ctypes.c_uint64, I, I, P]),
     "vmc_attention_vit_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "vmc_attention_vit_cls_fwd": (I, [P, P, P, I, I, I, I, P]),
     "vmc_attention_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, ctypes.c_uint64, I, P]),
     "vmc_attention_bwd_workspace_bytes": (Z, [I, I, I]),
     "vmc_attention_bwd": (I, [P] * 10 + [I] * 12 + [F, ctypes.c_uint64, P, Z, I, P]),

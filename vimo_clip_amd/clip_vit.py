@@ -94,6 +94,7 @@ class VisionTransformer(nn.Module):
         self._w16 = {}          # name -> (param version, 16-bit copy)
         self.fuse_add_ln = True  # False: x += GEMM in the epilogue (fp32 read-modify-write), plain LayerNorm after it
         self.cls_only_last_block = True  # last block's out_proj / MLP on the F class rows only (what ln_post reads)
+        self.cls_query_last_block = True  # ... and its attention for the class token's query only (vmc_attention_vit_cls_fwd)
         # x + attention branch not written back, the add+LN after c_proj redoes it (vmc_add2_layernorm_fwd: 22 instead of 24 B per
         # element and layer, bit-identical).  Measured 41.04 vs 40.98 ms per step: the saved fp32 write is paid back by re-reading a
         # branch that has left the caches -- off by default (profiles/README.md, round 2)
@@ -194,15 +195,27 @@ class VisionTransformer(nn.Module):
             last = i + 1 == len(blocks)
             if h is None:
                 h, *_ = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, dt16)
-            qkv = ops.linear(h, self.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
-            o, _ = ops.attention_vit(qkv, F, N, H)
-            del qkv
+            cls_query = last and self.cls_only_last_block and self.cls_query_last_block and trace is None
+            if cls_query:
+                # ... and of its attention only the class token's QUERY is needed (K and V of every token still are): the q third of
+                # in_proj runs on the F class rows, the attention on one query tile per (frame, head) instead of ceil(N / 16)
+                w_in, b_in = self.w16(pre + "in_proj", blk.attn.in_proj_weight), blk.attn.in_proj_bias
+                kv = ops.linear(h, w_in[D:], bias=b_in[D:])
+                q_cls = ops.linear(h.view(F, N, D)[:, 0, :], w_in[:D], bias=b_in[:D])
+                o = None
+                o_cls = ops.attention_vit_cls(q_cls, kv, F, N, H)
+                del kv, q_cls
+            else:
+                qkv = ops.linear(h, self.w16(pre + "in_proj", blk.attn.in_proj_weight), bias=blk.attn.in_proj_bias)
+                o, _ = ops.attention_vit(qkv, F, N, H)
+                del qkv
             if last and self.cls_only_last_block:
                 # Only x[:, 0] of the last block reaches ln_post (`x[:, 0, :]`, modeling_clip.py:650; OpenAI clip model.py
                 # `x = self.ln_post(x[:, 0, :])`): its out_proj, ln_2, MLP and residual adds are per-token maps, so they run on
                 # the F class rows instead of the F*N token rows -- the same arithmetic on 1/N of the rows (the attention itself
                 # still needs every token's K and V).  Saves two of the 96 large GEMMs and two add+LayerNorm passes per step.
-                o_cls = o.view(F, N, D)[:, 0, :]                      # strided rows (lda = N*D)
+                if o is not None:
+                    o_cls = o.view(F, N, D)[:, 0, :]                  # strided rows (lda = N*D)
                 x_cls = x.view(F, N, D)[:, 0, :]
                 if fused:
                     a = ops.linear(o_cls, self.w16(pre + "out_proj", blk.attn.out_proj.weight), bias=blk.attn.out_proj.bias)

@@ -104,9 +104,13 @@ __device__ __forceinline__ void attn_chunk(const char* k_lds, const char* v_lds,
   }
 }
 
+// q / k / v are given as separate bases with their own row strides (the packed in_proj output is q = qkv, k = qkv + D, v = qkv + 2D,
+// all with stride 3D); NQ <= N query rows per frame are processed (NQ = 1: only the class token's query, the last block of the
+// encoder, whose other rows nothing reads).
 template <typename T, int NT, int NC>
-__global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int H, float scale) {
+__global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                       const uint16_t* __restrict__ vp, uint16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int NQ, int H, size_t ldq, size_t ldkv, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKEYS = 16 * NT;
   char* const k_lds = smem;
@@ -116,8 +120,9 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   const int r = lane & 15, q = lane >> 4;
   const int f = blockIdx.x / H, h = blockIdx.x % H;
   const int D = H * 64;
-  const size_t ld = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)f * N * ld + h * 64;
+  const uint16_t* qbase = qp + (size_t)f * NQ * ldq + h * 64;
+  const uint16_t* kbase = kp + (size_t)f * N * ldkv + h * 64;
+  const uint16_t* vbase = vp + (size_t)f * N * ldkv + h * 64;
 
   // ---- stage K and V (zero rows for padded keys) ----
   // all loads first (NKEYS*8/256 <= 9 chunks of K and of V per thread, registers are free before the compute
@@ -131,9 +136,8 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
       const int row = idx >> 3, c = idx & 7;
       kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
       if (idx < NKEYS * 8 && row < N) {
-        const uint16_t* p = base + (size_t)row * ld + c * 8;
-        kreg[i] = *(const uint4*)(p + D);
-        vreg[i] = *(const uint4*)(p + 2 * D);
+        kreg[i] = *(const uint4*)(kbase + (size_t)row * ldkv + c * 8);
+        vreg[i] = *(const uint4*)(vbase + (size_t)row * ldkv + c * 8);
       }
     }
 #pragma unroll
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   __syncthreads();
 
   const float c2 = scale * 1.4426950408889634f;
-  const int nqt = (N + 15) >> 4;
+  const int nqt = (NQ + 15) >> 4;
   // per-lane LDS offsets; tile index / k-step only add compile-time constants (keeps address VGPRs low)
   const int koff0 = lds_off_x(r, q), koff1 = lds_off_x(r, 4 + q);
   int voff[4];
@@ -160,13 +164,13 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   // SIMD, so the long wave rotates with the block index instead of always landing on SIMD 0.
   const int w0 = (wave + blockIdx.x) & 3;
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(w0 * 16 + r, N - 1) * ld + (4 * kk + q) * 8);
+  for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(qbase + (size_t)min(w0 * 16 + r, NQ - 1) * ldq + (4 * kk + q) * 8);
   for (int qt = w0; qt < nqt; qt += 4) {
     const int qrow = qt * 16 + r;
     uint4 qf[2] = {qnext[0], qnext[1]};
     if (qt + 4 < nqt) {  // prefetch the next query tile's fragments under this tile's MFMAs
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(base + (size_t)min(qrow + 64, N - 1) * ld + (4 * kk + q) * 8);
+      for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(qbase + (size_t)min(qrow + 64, NQ - 1) * ldq + (4 * kk + q) * 8);
     }
 
     // Keys are processed in one or two chunks (online softmax across chunks): two chunks keep the live score
@@ -181,9 +185,9 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
     if constexpr (KS > KA) attn_chunk<T, KA, KS - KA, NC>(k_lds, v_lds, koff0, koff1, voff, qf, N, q, c2, m, o, osum);
     const float sum = osum[0];   // every accumulator row holds the full row sum of query r (16-bit rounded P, as P V uses)
     const float inv = 1.0f / sum;
-    if (lse != nullptr && q == 0 && qrow < N) lse[((size_t)f * H + h) * N + qrow] = m * scale + __logf(sum);
-    if (qrow < N) {
-      uint16_t* orow = out + ((size_t)f * N + qrow) * D + h * 64 + 4 * q;
+    if (lse != nullptr && q == 0 && qrow < NQ) lse[((size_t)f * H + h) * NQ + qrow] = m * scale + __logf(sum);
+    if (qrow < NQ) {
+      uint16_t* orow = out + ((size_t)f * NQ + qrow) * D + h * 64 + 4 * q;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *(uint2*)(orow + 16 * dt) = make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
@@ -191,8 +195,10 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   }
 }
 
+struct VitOperands { const uint16_t *q, *k, *v; size_t ldq, ldkv; int NQ; };
+
 template <typename T, int NT, int NC = 0>
-static int launch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t stream) {
+static int launch_vit(const VitOperands& a, void* out, float* lse, int F, int N, int H, hipStream_t stream) {
   auto kern = attn_vit_kernel<T, NT, NC>;
   constexpr int LDS = 16 * NT * 128 * 2;
   static bool attr_set = false;
@@ -201,13 +207,13 @@ static int launch_vit(const void* qkv, void* out, float* lse, int F, int N, int 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(F * H), dim3(256), LDS, stream, (const uint16_t*)qkv, (uint16_t*)out, lse, N, H, 0.125f);
+  hipLaunchKernelGGL(kern, dim3(F * H), dim3(256), LDS, stream, a.q, a.k, a.v, (uint16_t*)out, lse, N, a.NQ, H, a.ldq, a.ldkv, 0.125f);
   VMC_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T>
-static int dispatch_vit(const void* qkv, void* out, float* lse, int F, int N, int H, hipStream_t s) {
+static int dispatch_vit(const VitOperands& qkv, void* out, float* lse, int F, int N, int H, hipStream_t s) {
   if (N == 257) return launch_vit<T, 18, 257>(qkv, out, lse, F, N, H, s);   // ViT-L/14 @ 224
   if (N == 197) return launch_vit<T, 14, 197>(qkv, out, lse, F, N, H, s);   // ViT-B/16
   if (N == 50) return launch_vit<T, 4, 50>(qkv, out, lse, F, N, H, s);      // ViT-B/32
@@ -222,8 +228,20 @@ static int dispatch_vit(const void* qkv, void* out, float* lse, int F, int N, in
 extern "C" int vmc_attention_vit_fwd(const void* qkv, void* out, float* lse, int F, int N, int H, int dtype16, void* stream) {
   if (!qkv || !out || F <= 0 || N <= 0 || H <= 0) return VMC_E_ARG;
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return VMC_E_ALIGN;
-  if (dtype16 == VMC_BF16) return dispatch_vit<BF16>(qkv, out, lse, F, N, H, (hipStream_t)stream);
-  if (dtype16 == VMC_F16) return dispatch_vit<F16>(qkv, out, lse, F, N, H, (hipStream_t)stream);
+  const size_t D = (size_t)H * 64;
+  const VitOperands a = {(const uint16_t*)qkv, (const uint16_t*)qkv + D, (const uint16_t*)qkv + 2 * D, 3 * D, 3 * D, N};
+  if (dtype16 == VMC_BF16) return dispatch_vit<BF16>(a, out, lse, F, N, H, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return dispatch_vit<F16>(a, out, lse, F, N, H, (hipStream_t)stream);
+  return VMC_E_DTYPE;
+}
+
+extern "C" int vmc_attention_vit_cls_fwd(const void* q_cls, const void* kv, void* out, int F, int N, int H, int dtype16, void* stream) {
+  if (!q_cls || !kv || !out || F <= 0 || N <= 0 || H <= 0) return VMC_E_ARG;
+  if (((uintptr_t)q_cls | (uintptr_t)kv | (uintptr_t)out) & 15) return VMC_E_ALIGN;
+  const size_t D = (size_t)H * 64;
+  const VitOperands a = {(const uint16_t*)q_cls, (const uint16_t*)kv, (const uint16_t*)kv + D, D, 2 * D, 1};
+  if (dtype16 == VMC_BF16) return dispatch_vit<BF16>(a, out, nullptr, F, N, H, (hipStream_t)stream);
+  if (dtype16 == VMC_F16) return dispatch_vit<F16>(a, out, nullptr, F, N, H, (hipStream_t)stream);
   return VMC_E_DTYPE;
 }
 

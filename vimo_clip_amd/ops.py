@@ -167,6 +167,13 @@ def attention_vit(qkv: torch.Tensor, F: int, N: int, H: int, want_lse: bool = Fa
     return out, lse
 
 
+def attention_vit_cls(q_cls: torch.Tensor, kv: torch.Tensor, F: int, N: int, H: int) -> torch.Tensor:
+    """Attention of the class-token queries only: q_cls [F, D], kv [F*N, 2D] (K | V of every token) -> [F, D]."""
+    out = torch.empty((F, H * 64), dtype=kv.dtype, device=kv.device)
+    check(lib.vmc_attention_vit_cls_fwd(ptr(q_cls), ptr(kv), ptr(out), F, N, H, dt(kv), stream()), "attention_vit_cls_fwd")
+    return out
+
+
 def attention(q, k, v, key_mask_u8, B, H, Tq, Tk, dh, want_lse=False, dropout_p=0.0, dropout_seed=0):
     """Generic masked attention.  q/k/v are 2-D 16-bit views [B*T, ld] whose first H*dh columns are used."""
     out = torch.empty((B * Tq, H * dh), dtype=q.dtype, device=q.device)
