@@ -26,15 +26,28 @@ def main():
     ap.add_argument("--res32", action="store_true", help="fp32 residual in + fp32 out in place (out_proj / c_proj epilogue)")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (NOT a throughput figure: shows how much of the gap to "
                     "peak is data-dependent power / clock, cdna_hip_programming.md rule 25)")
+    ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "ones", "sparse90", "smallint"],
+                    help="operand values: randn (default, the throughput figure), zeros, ones (constant 1.0), sparse90 (randn with 90 %% of "
+                         "the elements zeroed), smallint (integers -2..2) -- everything but randn only shows the data dependence of the clock")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     for s in args.shapes:
         M, N, K = map(int, s.split(","))
         a = torch.randn(M, K, device="cuda").to(dt)
         w = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
-        if args.zeros:
+        fill = "zeros" if args.zeros else args.fill
+        if fill == "zeros":
             a.zero_()
             w.zero_()
+        elif fill == "ones":
+            a.fill_(1.0)
+            w.fill_(1.0)
+        elif fill == "sparse90":
+            a *= (torch.rand(M, K, device="cuda") < 0.1).to(dt)
+            w *= (torch.rand(N, K, device="cuda") < 0.1).to(dt)
+        elif fill == "smallint":
+            a = torch.randint(-2, 3, (M, K), device="cuda").to(dt)
+            w = torch.randint(-2, 3, (N, K), device="cuda").to(dt)
         out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if args.res32 else dt)
         bias = torch.randn(N, device="cuda")          # every encoder linear has one (and the persistent kernel takes bias linears)
         kw = dict(bias=bias, out=out, act=args.act, res=out if args.res32 else None)
