@@ -299,7 +299,12 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
   if (t256 >= 192) return launch_cfg<T, ACT, 8, 2, 4>(g, stream);
   if (t128 >= 128) return launch_cfg<T, ACT, 4, 2, 2>(g, stream);
-  return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);      // 64x64 tiles: latency-bound -> 4-stage ring
+  // 64x64 tiles: latency-bound -> 4-stage ring.  A workgroup streams its (BM + 64) x K operand bytes at the ~70 GB/s one CU pulls
+  // from L2, so a long K chain on few workgroups is bound by that: when 64-row tiles give at most 128 workgroups (the 256-row tail
+  // of c_proj: 4 x 16), 32-row tiles put twice as many CUs on it (same per-row arithmetic and K order: same bits; 27.3 -> 21.8 us at
+  // K = 4096, 9.6 -> 7.9 us at K = 1024; 16-row single-wave tiles were slower again: 25.5 / 8.8 us).
+  if ((long)((g.M + 63) / 64) * ((g.N + 63) / 64) <= 128 && g.K >= 1024) return launch_cfg<T, ACT, 1, 2, 1, 4>(g, stream);
+  return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);
 }
 
 template <typename T>
