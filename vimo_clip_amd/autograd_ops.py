@@ -166,10 +166,10 @@ class LinearFn(torch.autograd.Function):
         if b is not None and rows is not None:
             b = b[rows[0]:rows[1]]
         Nw = w16.shape[0]
-        if Nw % 8:                                 # odd output width (e.g. a 10- or 12-class head): zero rows up to 8n
-            if res is not None:
-                raise ValueError("LinearFn: a residual needs an output width that is a multiple of 8")
-            Np = (Nw + 7) // 8 * 8
+        if Nw % 4:                                 # odd output width (e.g. a 10-class head): zero rows up to 4n (vmc_linear: N % 4 == 0;
+            if res is not None:                    # the 140 Animal-Kingdom classes go through as they are)
+                raise ValueError("LinearFn: a residual needs an output width that is a multiple of 4")
+            Np = (Nw + 3) // 4 * 4
             wp = torch.zeros((Np, w16.shape[1]), dtype=dt16, device=x.device)
             wp[:Nw].copy_(w16)
             w16 = wp
