@@ -291,7 +291,8 @@ def tfam_extras(dev, rank, world, cdt):
     flops_clip = 1.0136e9
     B = 512
     try:
-        m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0,
+        # dropout 0.1 / 0.1 as the reference's cfg_AK/config_default.yaml:31-32 (active in the train legs only)
+        m = AMO_CLIP(d_model=768, nhead=8, num_layers=4, dim_feedforward=2048, num_classes=140, dropout=0.1, mlp_dropout=0.1,
                      device=dev, compute_dtype=cdt).to(dev)
         m.load_state_dict(synth.tfam_state_dict(768, 8, 4, 2048, 140, 4), strict=True)
         if world == 1:

@@ -279,6 +279,10 @@ int vmc_assemble_tokens(const void* xp, const float* cls, const float* pos, void
 /* Inverted dropout, y = x * keep/(1-p), keep(i) = hash(seed, i) >= p (nn.Dropout of
  * TFAM/models/AMO_CLIP.py:27-35,84).  Stateless: the backward applies the same call to dy. */
 int vmc_dropout(const void* x, void* y, size_t n, float p, uint64_t seed, int x_dtype, int dtype16, void* stream);
+/* y16 = cast(x * mask1/(1-p1) * mask2/(1-p2)) in one pass (p = 0 skips a mask): the backward of vmc_postnorm_dropout_fwd's branch,
+ * i.e. of `x + self.dropout(branch)` / the FFN's two trailing dropouts (AMO_CLIP.py:28,40,45,50), with the cast to the branch's type. */
+int vmc_cast_dropout2(const float* x, void* y16, size_t n, float p1, uint64_t seed1, float p2, uint64_t seed2, int dtype16,
+                      void* stream);
 /* y = x * scale[0], the scale read from device memory (the scalar gradient arriving at a loss node). */
 int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, const float* scale, void* stream);
 /* f32 <-> 16-bit casts on flat arrays. */

@@ -209,6 +209,48 @@ def test_attention_generic_masked(ops, dtype, B, H, Tq, Tk, dh):
     torch.testing.assert_close(out.float().cpu(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(3, 8, 16, 16, 96), (2, 4, 20, 33, 64), (2, 8, 16, 64, 96), (2, 2, 40, 200, 64)])
+def test_attention_with_probability_dropout(ops, dtype, B, H, Tq, Tk, dh):
+    """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), training) in the MFMA kernels (short sequences;
+    the last case is a long one on the generic fp32 kernels): forward and the three gradients against torch autograd with the SAME
+    mask, which is vmc_dropout's counter-based mask on the flat (batch, head, query, key) index -- obtained by running vmc_dropout
+    on a tensor of ones."""
+    from vimo_clip_amd import autograd_ops as ag
+    from vimo_clip_amd._lib import check, dt, lib, ptr, stream
+    D, p, seed = H * dh, 0.25, 0x1234567
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(B * Tq, D, generator=g).to(dtype)
+    kv = torch.randn(B * Tk, 2 * D, generator=g).to(dtype)
+    dout = torch.randn(B * Tq, D, generator=g).to(dtype)
+    lens = torch.randint(1, Tk + 1, (B,), generator=g)
+    lens[0] = Tk
+    mask = torch.arange(Tk)[None, :] < lens[:, None]
+    ones = torch.ones(B * H * Tq * Tk, device=DEV)
+    fac = torch.empty_like(ones)
+    check(lib.vmc_dropout(ptr(ones), ptr(fac), ones.numel(), p, seed, dt(ones), dt(dtype), stream()), "dropout")
+    fac = fac.view(B, H, Tq, Tk).cpu().double()
+    assert 0.1 < (fac == 0).double().mean().item() < 0.4
+    # reference in float64 with autograd
+    qf = q.double().view(B, Tq, H, dh).transpose(1, 2).requires_grad_(True)
+    kf = kv[:, :D].double().view(B, Tk, H, dh).transpose(1, 2).requires_grad_(True)
+    vf = kv[:, D:].double().view(B, Tk, H, dh).transpose(1, 2).requires_grad_(True)
+    sc = (qf @ kf.transpose(-1, -2)) / math.sqrt(dh)
+    sc = sc.masked_fill(~mask[:, None, None, :], float("-inf"))
+    o_ref = ((torch.softmax(sc, dim=-1) * fac) @ vf).transpose(1, 2).reshape(B * Tq, D)
+    o_ref.backward(dout.double())
+    # device
+    qd, kvd, dd, md = q.to(DEV), kv.to(DEV), dout.to(DEV), mask.to(torch.uint8).to(DEV)
+    out, lse = ops.attention(qd, kvd[:, :D], kvd[:, D:], md, B, H, Tq, Tk, dh, want_lse=True, dropout_p=p, dropout_seed=seed)
+    dq, dkv = torch.empty_like(qd), torch.empty_like(kvd)
+    ag._attn_bwd(qd, kvd[:, :D], kvd[:, D:], md, out, dd, lse, dq, dkv[:, :D], dkv[:, D:], B, H, Tq, Tk, dh, p=p, seed=seed)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    flat = lambda t, T_: t.detach().transpose(1, 2).reshape(B * T_, D)
+    for name, got, ref in (("out", out, o_ref.detach()), ("dq", dq, flat(qf.grad, Tq)), ("dk", dkv[:, :D], flat(kf.grad, Tk)), ("dv", dkv[:, D:], flat(vf.grad, Tk))):
+        err = (got.double().cpu() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (name, err)
+
+
 def test_attention_vit_matches_generic(ops):
     F, N, H = 2, 257, 4
     D = H * 64

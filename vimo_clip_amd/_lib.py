@@ -53,6 +53,7 @@ SIGNATURES = {
     "vmc_mean_pool_bwd": (I, [P, P, I, I, I, I, I, I, P]),
     "vmc_assemble_tokens": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vmc_dropout": (I, [P, P, Z, F, ctypes.c_uint64, I, I, P]),
+    "vmc_cast_dropout2": (I, [P, P, ctypes.c_size_t, F, ctypes.c_uint64, F, ctypes.c_uint64, I, P]),
     "vmc_attention_vit_fwd": (I, [P, P, P, I, I, I, I, P]),
     "vmc_attention_vit_cls_fwd": (I, [P, P, P, I, I, I, I, P]),
     "vmc_attention_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, ctypes.c_uint64, I, P]),

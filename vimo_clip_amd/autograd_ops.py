@@ -382,11 +382,12 @@ class PostNormFn(torch.autograd.Function):
         check(lib.vmc_layernorm_bwd(ptr(dy), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
                                     rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
         (p1, s1), (p2, s2) = ctx.drops
-        dbr = ops.cast16(dsum, dt16)
-        if p1 > 0.0:        # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds (in place on the 16-bit copy)
-            check(lib.vmc_dropout(ptr(dbr), ptr(dbr), dbr.numel(), float(p1), int(s1), dt(dbr), dt(dt16), stream()), "dropout")
-            if p2 > 0.0:
-                check(lib.vmc_dropout(ptr(dbr), ptr(dbr), dbr.numel(), float(p2), int(s2), dt(dbr), dt(dt16), stream()), "dropout")
+        if p1 > 0.0:        # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds, cast to the branch's type: one pass
+            dbr = torch.empty(dsum.shape, dtype=dt16, device=dsum.device)
+            check(lib.vmc_cast_dropout2(ptr(dsum), ptr(dbr), dsum.numel(), float(p1), int(s1), float(p2), int(s2), dt(dt16), stream()),
+                  "cast_dropout2")
+        else:
+            dbr = ops.cast16(dsum, dt16)
         return dsum, dbr, _deliver(gamma, dg), _deliver(beta, db), None, None
 
 

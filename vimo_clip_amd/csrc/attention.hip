@@ -255,7 +255,12 @@ template <typename T, int DH, int NT>
 __global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                         const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
                                                         uint16_t* __restrict__ op, float* __restrict__ lse, int H, int Tq, int Tk,
-                                                        int ldq, int ldk, int ldv, int ldo, float scale) {
+                                                        int ldq, int ldk, int ldv, int ldo, float scale, float drop_p,
+                                                        uint64_t seed_arg) {
+  // drop_p > 0: nn.MultiheadAttention's dropout on the attention probabilities (AMO_CLIP.py:37-45, training): the softmax is
+  // normalised by the sum of the UNdropped probabilities, P V uses p * keep / (1 - drop_p) with vmc_dropout's counter-based mask on
+  // the flat index of (batch, head, query, key) -- the same masks as the generic fp32 kernels, regenerated by the backward.
+  const uint64_t seed = drop_p > 0.f ? resolve_seed(seed_arg) : 0;
   constexpr int NKEYS = 16 * NT, CH = DH / 8, RS = DH * 2 + 16, KK = DH / 32, DT = DH / 16;
   __shared__ __attribute__((aligned(16))) char k_lds[NKEYS * RS];
   __shared__ __attribute__((aligned(16))) char v_lds[NKEYS * RS];
@@ -328,12 +333,23 @@ __global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restri
 #pragma unroll
     for (int ks = 0; ks < NT / 2; ++ks) {
       const f32x4 a = s[2 * ks], bb = s[2 * ks + 1];
-      uint4 pf;
-      pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[1], c2, -mc)));
-      pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(a[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(a[3], c2, -mc)));
-      pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(bb[0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(bb[1], c2, -mc)));
-      pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(bb[2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(bb[3], c2, -mc)));
+      float pe[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pe[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(a[j], c2, -mc));
+        pe[4 + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(bb[j], c2, -mc));
+      }
+      uint4 pf = make_uint4(pack2<T>(pe[0], pe[1]), pack2<T>(pe[2], pe[3]), pack2<T>(pe[4], pe[5]), pack2<T>(pe[6], pe[7]));
       osum = T::mfma16(ones, pf, osum);
+      if (drop_p > 0.f) {                      // wave-uniform
+        const size_t base = (((size_t)b * H + h) * Tq + min(qrow, Tq - 1)) * Tk + 32 * ks + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pe[j] *= dropout_factor(drop_p, seed, base + j);
+          pe[4 + j] *= dropout_factor(drop_p, seed, base + 16 + j);
+        }
+        pf = make_uint4(pack2<T>(pe[0], pe[1]), pack2<T>(pe[2], pe[3]), pack2<T>(pe[4], pe[5]), pack2<T>(pe[6], pe[7]));
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         // transposed 4-key x 16-column blocks: this lane supplies key row 32 ks + 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
@@ -360,10 +376,10 @@ __global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restri
 
 template <typename T>
 static int launch_small(const void* q, const void* k, const void* v, const uint8_t* mask, void* out, float* lse, int B, int H, int Tq,
-                        int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t s) {
+                        int Tk, int dh, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p, uint64_t seed, hipStream_t s) {
 #define VMC_SMALL(DHV, NTV)                                                                                                      \
   hipLaunchKernelGGL((attn_small_kernel<T, DHV, NTV>), dim3(B * H), dim3(64), 0, s, (const uint16_t*)q, (const uint16_t*)k,      \
-                     (const uint16_t*)v, mask, (uint16_t*)out, lse, H, Tq, Tk, ldq, ldk, ldv, ldo, scale)
+                     (const uint16_t*)v, mask, (uint16_t*)out, lse, H, Tq, Tk, ldq, ldk, ldv, ldo, scale, drop_p, seed)
   if (dh == 64 && Tk <= 32) VMC_SMALL(64, 2);
   else if (dh == 64) VMC_SMALL(64, 4);
   else if (dh == 96 && Tk <= 32) VMC_SMALL(96, 2);
@@ -546,7 +562,10 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqp,
                                                             uint16_t* __restrict__ dkp, uint16_t* __restrict__ dvp, int H, int Tq,
                                                             int Tk, int ldq, int ldk, int ldv, int ldo, int lddq, int lddk, int lddv,
-                                                            float scale, int RS) {
+                                                            float scale, int RS, float drop_p, uint64_t seed_arg) {
+  // drop_p > 0 (dropout on the probabilities, forward above): with f = keep / (1 - drop_p) regenerated from the seed,
+  // dV = (P f)^T dO,  dS = P (dP f - delta),  delta = rowsum(dO O) as without dropout.
+  const uint64_t seed = drop_p > 0.f ? resolve_seed(seed_arg) : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = DH / 8, KK = DH / 32, DT = DH / 16;
   const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;       // padded to whole 32-row steps (zero rows)
@@ -639,8 +658,9 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
         for (int j = 0; j < 4; ++j) {
           const int qi = 16 * qt + 4 * g + j;
           const float p = (klive && qi < Tq) ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], c2, -lse_s[qi])) : 0.f;
-          pv[j] = p;
-          dv4[j] = p * (dp[j] - del_s[qi]);
+          const float f = drop_p > 0.f ? dropout_factor(drop_p, seed, (((size_t)b * H + h) * Tq + min(qi, Tq - 1)) * Tk + min(key, Tk - 1)) : 1.0f;
+          pv[j] = p * f;
+          dv4[j] = p * (dp[j] * f - del_s[qi]);
         }
         pp[2 * half] = pack2<T>(pv[0], pv[1]); pp[2 * half + 1] = pack2<T>(pv[2], pv[3]);
         dd[2 * half] = pack2<T>(dv4[0], dv4[1]); dd[2 * half + 1] = pack2<T>(dv4[2], dv4[3]);
@@ -704,7 +724,8 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
           const int key = 16 * nt + 4 * g + j;
           const bool live = qlive && key < Tk && (mask == nullptr || mask[(size_t)b * Tk + key] != 0);
           const float p = live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], c2, -l2)) : 0.f;
-          dv4[j] = p * (dp[j] - dl);
+          const float f = drop_p > 0.f ? dropout_factor(drop_p, seed, (((size_t)b * H + h) * Tq + min(qi, Tq - 1)) * Tk + min(key, Tk - 1)) : 1.0f;
+          dv4[j] = p * (dp[j] * f - dl);
         }
         dd[2 * half] = pack2<T>(dv4[0], dv4[1]); dd[2 * half + 1] = pack2<T>(dv4[2], dv4[3]);
       }
@@ -730,7 +751,7 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
 template <typename T, int DH>
 static int launch_bwd_mfma(const void* q, const void* k, const void* v, const uint8_t* mask, const void* out, const void* dout,
                            const float* lse, void* dq, void* dk, void* dv, int B, int H, int Tq, int Tk, int ldq, int ldk, int ldv,
-                           int ldo, int lddq, int lddk, int lddv, float scale, hipStream_t s) {
+                           int ldo, int lddq, int lddk, int lddv, float scale, float drop_p, uint64_t seed, hipStream_t s) {
   const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;
   int RS = DH * 2 + 16;
   size_t lds = (size_t)2 * (TQP + TKP) * RS + (size_t)2 * TQP * sizeof(float);
@@ -748,7 +769,7 @@ static int launch_bwd_mfma(const void* q, const void* k, const void* v, const ui
   }
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, mask,
                      (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, H, Tq, Tk, ldq, ldk,
-                     ldv, ldo, lddq, lddk, lddv, scale, RS);
+                     ldv, ldo, lddq, lddk, lddv, scale, RS, drop_p, seed);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -768,9 +789,9 @@ extern "C" int vmc_attention_fwd(const void* q, const void* k, const void* v, co
   if (rc) return rc;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return VMC_E_ALIGN;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (dropout_p == 0.f && Tk <= 64 && (dh == 64 || dh == 96) && (ldo % 4) == 0) {   // short sequences: MFMA kernel, one wave per (b, h)
-    if (dtype16 == VMC_BF16) return launch_small<BF16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
-    if (dtype16 == VMC_F16) return launch_small<F16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+  if (Tk <= 64 && (dh == 64 || dh == 96) && (ldo % 4) == 0) {   // short sequences: MFMA kernel, one wave per (b, h)
+    if (dtype16 == VMC_BF16) return launch_small<BF16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, (hipStream_t)stream);
+    if (dtype16 == VMC_F16) return launch_small<F16>(q, k, v, key_mask, out, lse, B, H, Tq, Tk, dh, ldq, ldk, ldv, ldo, scale, dropout_p, dropout_seed, (hipStream_t)stream);
     return VMC_E_DTYPE;
   }
   dim3 grid(B * H * Tq);
@@ -801,16 +822,16 @@ extern "C" int vmc_attention_bwd(const void* q, const void* k, const void* v, co
   if (workspace_bytes < vmc_attention_bwd_workspace_bytes(B, H, Tq)) return VMC_E_ARG;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) return VMC_E_ALIGN;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (dropout_p == 0.f && (dh == 64 || dh == 96) && ((lddq | lddk | lddv | ldo) % 4) == 0) {   // MFMA path when the head fits in LDS
+  if ((dh == 64 || dh == 96) && ((lddq | lddk | lddv | ldo) % 4) == 0) {   // MFMA path when the head fits in LDS
     const int TQP = (Tq + 31) & ~31, TKP = (Tk + 31) & ~31;
     if ((size_t)2 * (TQP + TKP) * dh * 2 + (size_t)2 * TQP * sizeof(float) <= 160 * 1024) {
       hipStream_t st = (hipStream_t)stream;
       if (dtype16 == VMC_BF16)
-        return dh == 64 ? launch_bwd_mfma<BF16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st)
-                        : launch_bwd_mfma<BF16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st);
+        return dh == 64 ? launch_bwd_mfma<BF16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, dropout_p, dropout_seed, st)
+                        : launch_bwd_mfma<BF16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, dropout_p, dropout_seed, st);
       if (dtype16 == VMC_F16)
-        return dh == 64 ? launch_bwd_mfma<F16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st)
-                        : launch_bwd_mfma<F16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, st);
+        return dh == 64 ? launch_bwd_mfma<F16, 64>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, dropout_p, dropout_seed, st)
+                        : launch_bwd_mfma<F16, 96>(q, k, v, key_mask, out, dout, lse, dq, dk, dv, B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, dropout_p, dropout_seed, st);
       return VMC_E_DTYPE;
     }
   }

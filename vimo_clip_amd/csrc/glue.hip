@@ -80,6 +80,34 @@ extern "C" int vmc_dropout(const void* x, void* y, size_t n, float p, uint64_t s
   VMC_DISPATCH16(dropout_kernel, grid_for(n, 256), x, y, n, p, seed, x_dtype == VMC_F32)
 }
 
+// y16 = cast(x32 * keep1/(1-p1) * keep2/(1-p2)): the gradient of a branch that went through one or two dropouts in front of a post-norm
+// LayerNorm (vmc_postnorm_dropout_fwd), cast to the branch's 16-bit type in the same pass (was: a cast and one launch per dropout).
+template <typename T>
+__global__ void cast_dropout2_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n, float p1, uint64_t seed1_arg, float p2,
+                                     uint64_t seed2_arg) {
+  const uint64_t seed1 = p1 > 0.f ? resolve_seed(seed1_arg) : 0, seed2 = p2 > 0.f ? resolve_seed(seed2_arg) : 0;
+  const uint32_t thr1 = (uint32_t)((double)p1 * 4294967296.0), thr2 = (uint32_t)((double)p2 * 4294967296.0);
+  const float sc1 = 1.0f / (1.0f - p1), sc2 = 1.0f / (1.0f - p2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (p1 > 0.f) v = hash32(seed1, i) >= thr1 ? v * sc1 : 0.0f;
+    if (p2 > 0.f) v = hash32(seed2, i) >= thr2 ? v * sc2 : 0.0f;
+    y[i] = T::from_f32(v);
+  }
+}
+extern "C" int vmc_cast_dropout2(const float* x, void* y16, size_t n, float p1, uint64_t seed1, float p2, uint64_t seed2, int dtype16,
+                                 void* stream) {
+  if (!x || !y16 || n == 0 || p1 < 0.f || p1 >= 1.f || p2 < 0.f || p2 >= 1.f) return VMC_E_ARG;
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(cast_dropout2_kernel<BF16>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y16, n, p1, seed1, p2, seed2);
+  else if (dtype16 == VMC_F16)
+    hipLaunchKernelGGL(cast_dropout2_kernel<F16>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y16, n, p1, seed1, p2, seed2);
+  else
+    return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
 // y = x * (*scale)   with the scale read from device memory (incoming scalar gradient of a loss)
 __global__ void scale_dev_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, const float* __restrict__ scale) {
   const float s = scale[0];
