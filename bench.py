@@ -359,8 +359,9 @@ def tfam_extras(dev, rank, world, cdt):
     return out
 
 
-def tfam_small_batch_train(dev, cdt, m, batches=(8, 64), iters=50):
-    """The reference's own batch size (TFAM/train_and_eval.py:34 batch_size = 8 per GPU) is launch-bound: ~230 launches per step.
+def tfam_small_batch_train(dev, cdt, m, batches=(8, 64, 512), iters=30):
+    """The reference's own batch size (TFAM/train_and_eval.py:34 batch_size = 8 per GPU) is launch-bound: ~240 launches per step (and at
+    B = 512 the eager step is still bound by the host's launch rate on a slow host: the captured figure is the GPU's).
     Eager step vs ONE hipGraph replay per step (graphs.GraphedTrainStep: step count, lr, bias corrections and dropout seeds in
     device memory, advanced by vmc_train_tick inside the graph).  Single process; wall clock around synchronised loops."""
     from vimo_clip_amd import synth
