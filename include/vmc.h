@@ -206,6 +206,13 @@ int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx,
                       int dy_dtype, int x_dtype, int dx_dtype, int dtype16, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same with TWO incoming gradients dy + dy2 (dy2 16-bit [rows, D], may be NULL): a post-norm LayerNorm output feeds both the fp32
+ * residual path and the 16-bit GEMM operand of the next sub-layer (AMO_CLIP.py:40-50), so its backward receives one gradient of each
+ * type; summed in fp32 inside the kernel (was: a separate add pass). */
+int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx,
+                       int dy_dtype, int x_dtype, int dx_dtype, int dtype16, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4 — ViT self-attention  softmax(Q K^T / sqrt(dh)) V, no mask, head_dim 64 (MFMA, K/V tile in LDS).

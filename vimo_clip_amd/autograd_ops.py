@@ -369,18 +369,21 @@ class PostNormFn(torch.autograd.Function):
         gamma, beta, dt16 = ctx.gamma, ctx.beta, ctx.dt16
         D = gamma.shape[0]
         rows = ssum.numel() // D
+        dy2 = None
         if dy32 is None:
             dy = dy16.contiguous()
         elif dy16 is None:
             dy = dy32.contiguous()
-        else:
-            dy = _add(dy32.contiguous(), dy16.contiguous(), torch.float32, dt16)
+        else:                                   # both consumers sent a gradient: summed in fp32 inside the LayerNorm backward
+            dy, dy2 = dy32.contiguous(), dy16.contiguous()
+            if dy2.dtype != dt16:
+                dy, dy2 = _add(dy, dy2, torch.float32, dt16), None
         dsum = torch.empty_like(ssum)
         dg, db = _grad_out(gamma, (D,)), _grad_out(beta, (D,))
         nbytes = lib.vmc_layernorm_bwd_workspace_bytes(rows, D)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=ssum.device)
-        check(lib.vmc_layernorm_bwd(ptr(dy), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
-                                    rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd")
+        check(lib.vmc_layernorm_bwd2(ptr(dy), ptr(dy2), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
+                                     rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd2")
         (p1, s1), (p2, s2) = ctx.drops
         if p1 > 0.0:        # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds, cast to the branch's type: one pass
             dbr = torch.empty(dsum.shape, dtype=dt16, device=dsum.device)

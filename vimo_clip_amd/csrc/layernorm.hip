@@ -353,7 +353,7 @@ extern "C" int vmc_postnorm_fwd(const float* x, const void* branch, const float*
 // row needs (D = 768: 3 chunks instead of 8), which leaves room to fetch the NEXT row of this wave while the current one
 // is reduced and written (one row per wave in flight was the limit: 3.2 TB/s).
 template <typename T, int NCH>
-__global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ dy2, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      const void* __restrict__ addp, float* __restrict__ partial, int rows,
@@ -380,6 +380,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
       const int col = c * 256 + lane * 4;
       if (col < D) {
         ngy[c] = load4<T>(dy, (size_t)row * D + col, dy_f32);
+        if (dy2) {            // a second incoming gradient (16-bit): the LayerNorm output was consumed as fp32 residual AND as 16-bit operand
+          const float4 t = load4<T>(dy2, (size_t)row * D + col, 0);
+          ngy[c].x += t.x; ngy[c].y += t.y; ngy[c].z += t.z; ngy[c].w += t.w;
+        }
         nxv[c] = load4<T>(x, (size_t)row * ldx + col, x_f32);
         if (addp) nad[c] = load4<T>(addp, (size_t)row * D + col, dx_f32);
       }
@@ -479,9 +483,18 @@ extern "C" size_t vmc_layernorm_bwd_workspace_bytes(int rows, int D) {
   return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
 }
 
+extern "C" int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                                  int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                  const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
                                  int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
+  return vmc_layernorm_bwd2(dy, nullptr, x, gamma, mean, rstd, add, dx, dgamma, dbeta, rows, D, ldx, dy_dtype, x_dtype, dx_dtype, dtype16,
+                            workspace, workspace_bytes, stream);
+}
+extern "C" int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                                  int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return VMC_E_ARG;
   if (D % 4 || D > LN_BWD_MAX_CHUNKS * 256) return VMC_E_SHAPE;
   if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
@@ -493,10 +506,10 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
 #define VMC_LN_BWD(NCH)                                                                                                          \
   do {                                                                                                                           \
     if (dtype16 == VMC_BF16)                                                                                                     \
-      hipLaunchKernelGGL((ln_bwd_kernel<BF16, NCH>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add,           \
+      hipLaunchKernelGGL((ln_bwd_kernel<BF16, NCH>), dim3(grid), dim3(256), lds, s, dy, dy2, x, gamma, mean, rstd, dx, add,      \
                          (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
     else                                                                                                                         \
-      hipLaunchKernelGGL((ln_bwd_kernel<F16, NCH>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, add,            \
+      hipLaunchKernelGGL((ln_bwd_kernel<F16, NCH>), dim3(grid), dim3(256), lds, s, dy, dy2, x, gamma, mean, rstd, dx, add,       \
                          (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
   } while (0)
   if (D <= 512) VMC_LN_BWD(2);
