@@ -51,6 +51,7 @@ def test_linear_exact_integers(ops, dtype, M, N, K):
     (16384, 4096, 384, 1),       # 1024 tiles = 4 per workgroup, head / steady / roll, QuickGELU
     (65792, 1024, 512, 3),       # ViT-L/14 row count: 1024 persistent tiles + the 256-row tail launch, ReLU
     (8192, 8192, 1024, 0),       # 1024 tiles, 16 K tiles
+    (21760, 768, 768, 0),        # 255 tiles (the main part of the student's 300-tile GEMMs): fewer tiles than workgroups, one walk each
 ])
 def test_linear_persistent_walk(ops, dtype, M, N, K, act):
     """Persistent 8-phase GEMM (whole 256x256 tiles, bias, 16-bit output: what vmc_linear takes for the encoder's big linears).

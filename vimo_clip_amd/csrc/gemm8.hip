@@ -508,6 +508,7 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
 
   const int nkt = g.K >> 6;   // even, >= 4 (checked by the launcher)
   int bid = blockIdx.x, tm, tn;
+  if (bid >= ntiles) return;  // fewer tiles than workgroups (192 .. 255 tiles: one tile each, the epilogue overlap is still worth it)
   g8_tile_coords(g, xcd_remap(bid, ntiles), tm, tn);
   G8Panel cur = {(uint32_t)tm * TA, (uint32_t)tn * TB};
   // prologue of the first tile: same issue order as the steady state so the vmcnt accounting holds from the first phase
@@ -608,12 +609,12 @@ static int g8p_launch(GemmArgs& g, hipStream_t stream) {
   return 0;
 }
 
-// The persistent kernel takes problems made of whole 256x256 tiles (at least one per CU, at least two K iterations) with a
+// The persistent kernel takes problems made of whole 256x256 tiles (at least 192 of them, at least two K iterations) with a
 // plain 16-bit output: the encoders' qkv / out_proj / c_fc / c_proj (bias), the same with the pre-activation side output of
 // training (QuickGELU c_fc), and the bias-free input-gradient GEMMs.  Everything else -- fp32 residual epilogue, row remaps,
 // other activation / side-output combinations -- runs one tile per workgroup.
 static bool g8p_eligible(const GemmArgs& g) {
-  if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 256 || g.K < 256) return false;
+  if ((g.M & 255) || (g.N & 255) || (long)(g.M / 256) * (g.N / 256) < 192 || g.K < 256) return false;
   if ((size_t)g.M * g.lda * 2 >= (1ull << 31) || (size_t)g.N * g.ldw * 2 >= (1ull << 31)) return false;   // buffer descriptors / 32-bit offsets
   if ((size_t)255 * g.ldc * 2 + 512 >= (1ull << 31) || (g.zout && g.ldz != g.ldc)) return false;
   return g8_epi_kind(g) == G8_EPI_STORE16;
