@@ -149,6 +149,21 @@ __global__ void __launch_bounds__(256) patches_u8_exact_kernel(const uint8_t* __
     const int f = (int)(t / 3);
     const uint32_t px = *(const uint32_t*)(frames + i * 4);
     const int py = y / p, dy = y % p;
+    if ((p & 1) == 0) {        // even patch size (14 / 16 / 32): a pixel pair at an even x never straddles a patch -> 4-byte stores
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int x = xq * 4 + j;
+        uint32_t v0 = (px >> (8 * j)) & 0xFFu, v1 = (px >> (8 * j + 8)) & 0xFFu;
+        if (wrap) { v0 = (256u - v0) & 0xFFu; v1 = (256u - v1) & 0xFFu; }
+        const int pxi = x / p, dx = x % p;
+        const size_t prow = ((size_t)f * g + py) * g + pxi;
+        const uint32_t h2 = (uint32_t)T::from_f32((float)v0) | ((uint32_t)T::from_f32((float)v1) << 16);
+        uint16_t* dst = patches + prow * (2 * (size_t)kpad) + (c * p + dy) * p + dx;
+        *(uint32_t*)dst = h2;
+        *(uint32_t*)(dst + kpad) = h2;
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int x = xq * 4 + j;
