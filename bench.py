@@ -606,6 +606,13 @@ def main():
                     t_, b_ = sum(t for t, _ in sel), sum(b for _, b in sel)
                     sec[name] = {"bound": "hbm", "achieved": round(b_ / t_ / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(b_ / t_ / 8e12, 4), "launches": len(sel), "avg_launch_ms": round(1e3 * t_ / len(sel), 4)}
+            try:    # HBM bytes per launch of the two kernels from the committed rocprofv3 --pmc passes (tools/_prof_r02b.sh)
+                with open(os.path.join(ROOT, "profiles", "r02_secondary_traffic.json")) as f:
+                    sec_traffic = json.load(f)
+                for name in sec:
+                    sec[name]["traffic"] = sec_traffic.get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             result["secondary_rooflines"] = sec
             big = [(s.elapsed_time(e) * 1e-3, f) for s, e, f, is_big in events if is_big]
             t_big = sum(t for t, _ in big)
