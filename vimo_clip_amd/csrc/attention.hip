@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64) attn_generic_bwd_kv(const uint16_t* __rest
 // is computed in the prologue.  Rows of the LDS images are padded by 16 B when they fit, else unpadded.
 // ==================================================================================================
 template <typename T, int DH>
-__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+__global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                             const uint16_t* __restrict__ vp, const uint8_t* __restrict__ mask,
                                                             const uint16_t* __restrict__ op, const uint16_t* __restrict__ dop,
                                                             const float* __restrict__ lse, uint16_t* __restrict__ dqp,
@@ -601,12 +601,16 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
     *(uint4*)(k_lds + row * RS + c * 16) = a;
     *(uint4*)(v_lds + row * RS + c * 16) = d;
   }
-  for (int row = tid; row < TQP; row += 256) {
-    float dl = 0.f, l2 = 0.f;
+  // delta = rowsum(dO * O): four lanes per row (column chunks c = part, part + 4, ...), summed by two shuffles -- sixteen threads walking
+  // a whole row each left the other 240 waiting at the barrier (T = 16: the TFAM shapes)
+  for (int item = tid; item < TQP * 4; item += 256) {
+    const int row = item >> 2, part = item & 3;
+    float dl = 0.f;
     if (row < Tq) {
       const uint16_t* o = op + (qrow0 + row) * ldo + h * DH;
       const uint16_t* d = dop + (qrow0 + row) * ldo + h * DH;
-      for (int c = 0; c < DH; c += 8) {
+#pragma unroll
+      for (int c = 8 * part; c < DH; c += 32) {
         const uint4 ow = *(const uint4*)(o + c), dw = *(const uint4*)(d + c);
         const uint32_t oa[4] = {ow.x, ow.y, ow.z, ow.w}, da[4] = {dw.x, dw.y, dw.z, dw.w};
 #pragma unroll
@@ -617,18 +621,27 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
           dl += o0 * d0 + o1 * d1;
         }
       }
-      l2 = lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f;
     }
-    del_s[row] = dl;
-    lse_s[row] = l2;
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    if (part == 0) {
+      del_s[row] = dl;
+      lse_s[row] = row < Tq ? lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f : 0.f;
+    }
   }
   __syncthreads();
 
   const float c2 = scale * 1.4426950408889634f;
   const int nkt = TKP >> 4, nqt = TQP >> 4;
+  // Tiles with at least one real row.  Phase A (a key tile -> dK, dV) and phase B (a query tile -> dQ) only read the LDS images, so
+  // they are independent TASKS dealt round-robin to the four waves: at T = 16 (one live tile each way) waves 0 and 1 run the two
+  // phases side by side instead of one after the other, and all-padding tiles (rows 16..31 of a 16-token clip) are not computed.
+  const int nktL = (Tk + 15) >> 4, nqtL = (Tq + 15) >> 4;
 
+  for (int task = wave; task < nktL + nqtL; task += 4) {
+  if (task < nktL) {
   // ================= phase A: dK, dV =================
-  for (int nt = wave; nt < nkt; nt += 4) {
+    const int nt = task;
     const int key = 16 * nt + r;                               // this lane's key column
     const bool klive = key < Tk && (mask == nullptr || mask[(size_t)b * Tk + key] != 0);
     uint4 kf[KK], vf[KK];
@@ -689,10 +702,9 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
         *(uint2*)(dkr + 16 * dt) = make_uint2(pack2<T>(dkt[dt][0] * scale, dkt[dt][1] * scale), pack2<T>(dkt[dt][2] * scale, dkt[dt][3] * scale));
       }
     }
-  }
-
+  } else {
   // ================= phase B: dQ =================
-  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qt = task - nktL;
     const int qi = 16 * qt + r;                                // this lane's query column
     const bool qlive = qi < Tq;
     const float l2 = lse_s[qi], dl = del_s[qi];
@@ -746,6 +758,7 @@ __global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const uint16_t* __re
         *(uint2*)(dqr + 16 * dt) = make_uint2(pack2<T>(dqt[dt][0] * scale, dqt[dt][1] * scale), pack2<T>(dqt[dt][2] * scale, dqt[dt][3] * scale));
     }
   }
+  }  // tasks
 }
 
 template <typename T, int DH>
