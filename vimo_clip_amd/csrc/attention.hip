@@ -576,12 +576,13 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
   float* const lse_s = (float*)(v_lds + TKP * RS);                // [TQP] log2-domain lse: lse * log2(e)
   float* const del_s = lse_s + TQP;                               // [TQP] delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;      // 1 .. 4 waves: as many as there are tile tasks (launch_bwd_mfma)
   const int r = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const size_t qrow0 = (size_t)b * Tq, krow0 = (size_t)b * Tk;
 
   // ---- stage Q, dO, K, V (zero padding rows); delta and lse ----
-  for (int idx = tid; idx < TQP * CH; idx += 256) {
+  for (int idx = tid; idx < TQP * CH; idx += nthr) {
     const int row = idx / CH, c = idx % CH;
     uint4 a = make_uint4(0, 0, 0, 0), d = a;
     if (row < Tq) {
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
     *(uint4*)(q_lds + row * RS + c * 16) = a;
     *(uint4*)(do_lds + row * RS + c * 16) = d;
   }
-  for (int idx = tid; idx < TKP * CH; idx += 256) {
+  for (int idx = tid; idx < TKP * CH; idx += nthr) {
     const int row = idx / CH, c = idx % CH;
     uint4 a = make_uint4(0, 0, 0, 0), d = a;
     if (row < Tk) {
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
   }
   // delta = rowsum(dO * O): four lanes per row (column chunks c = part, part + 4, ...), summed by two shuffles -- sixteen threads walking
   // a whole row each left the other 240 waiting at the barrier (T = 16: the TFAM shapes)
-  for (int item = tid; item < TQP * 4; item += 256) {
+  for (int item = tid; item < TQP * 4; item += nthr) {
     const int row = item >> 2, part = item & 3;
     float dl = 0.f;
     if (row < Tq) {
@@ -634,11 +635,11 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
   const float c2 = scale * 1.4426950408889634f;
   const int nkt = TKP >> 4, nqt = TQP >> 4;
   // Tiles with at least one real row.  Phase A (a key tile -> dK, dV) and phase B (a query tile -> dQ) only read the LDS images, so
-  // they are independent TASKS dealt round-robin to the four waves: at T = 16 (one live tile each way) waves 0 and 1 run the two
+  // they are independent TASKS dealt round-robin to the workgroup's waves (launched: min(4, tasks)): at T = 16 (one live tile each way) waves 0 and 1 run the two
   // phases side by side instead of one after the other, and all-padding tiles (rows 16..31 of a 16-token clip) are not computed.
   const int nktL = (Tk + 15) >> 4, nqtL = (Tq + 15) >> 4;
 
-  for (int task = wave; task < nktL + nqtL; task += 4) {
+  for (int task = wave; task < nktL + nqtL; task += nwaves) {
   if (task < nktL) {
   // ================= phase A: dK, dV =================
     const int nt = task;
@@ -780,7 +781,11 @@ static int launch_bwd_mfma(const void* q, const void* k, const void* v, const ui
     if (e != hipSuccess) return (int)e;
     attr = 160 * 1024;
   }
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, mask,
+  // one wave per tile task, at most four: a 16-token clip (one key tile + one query tile) runs as a 2-wave workgroup, which lets
+  // five of them share a CU instead of three 4-wave ones with two idle waves each
+  const int tasks = (Tk + 15) / 16 + (Tq + 15) / 16;
+  const int threads = 64 * (tasks < 4 ? tasks : 4);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(threads), lds, s, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, mask,
                      (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dq, (uint16_t*)dk, (uint16_t*)dv, H, Tq, Tk, ldq, ldk,
                      ldv, ldo, lddq, lddk, lddv, scale, RS, drop_p, seed);
   VMC_CHECK_LAUNCH();
