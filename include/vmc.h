@@ -213,6 +213,14 @@ int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const flo
                        const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx,
                        int dy_dtype, int x_dtype, int dx_dtype, int dtype16, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* Backward of vmc_postnorm_dropout_fwd in one launch (+ the partial reduce of dgamma / dbeta): with the saved pre-norm sum, mean and rstd,
+ *   dsum (f32 [rows, D])       = LayerNorm'(dy + dy2)            (dy f32 or 16-bit, dy2 16-bit or NULL, as vmc_layernorm_bwd2)
+ *   dbranch16 (16-bit [rows, D]) = cast(dsum * mask1/(1-p1) * mask2/(1-p2))   (the forward's masks, regenerated from the seeds)
+ * i.e. what vmc_layernorm_bwd2 followed by vmc_cast_dropout2 (p = 0: a plain cast) computes, bit for bit, without the second pass over
+ * the gradient (autograd of `norm(x + dropout(branch))`, TFAM/models/AMO_CLIP.py:40-50 under TFAM/train_and_eval.py:83). */
+int vmc_postnorm_bwd(const void* dy, const void* dy2, const float* sum, const float* gamma, const float* mean, const float* rstd,
+                     float* dsum, void* dbranch16, float* dgamma, float* dbeta, int rows, int D, int dy_dtype, float p1,
+                     uint64_t seed1, float p2, uint64_t seed2, int dtype16, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4 — ViT self-attention  softmax(Q K^T / sqrt(dh)) V, no mask, head_dim 64 (MFMA, K/V tile in LDS).

@@ -360,6 +360,37 @@ def test_tfam_fused_dropout_tail_matches_unfused_path():
         assert num <= tol * den + 1e-6, (k, num, den)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("drops", [((0.0, 0), (0.0, 0)), ((0.3, 77), (0.0, 0)), ((0.1, 5), (0.2, 9))])
+@pytest.mark.parametrize("rows,D,two", [(128, 768, True), (8192, 768, False), (77, 512, True), (1000, 256, True)])
+def test_postnorm_backward_in_one_launch_equals_the_two_pass_backward(rows, D, two, drops, dtype):
+    """vmc_postnorm_bwd (LayerNorm backward + the branch gradient through the regenerated dropout masks, cast to 16 bits, from one store
+    loop) == vmc_layernorm_bwd2 followed by vmc_cast_dropout2 / the plain cast, bit for bit: d sum, d branch, d gamma, d beta."""
+    from vimo_clip_amd import autograd_ops as ag
+    g = torch.Generator().manual_seed(rows + D)
+    x32 = torch.randn(rows, D, generator=g).cuda()
+    br = torch.randn(rows, D, generator=g).to(dtype).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    dy32 = torch.randn(rows, D, generator=g).cuda()
+    dy16 = torch.randn(rows, D, generator=g).to(dtype).cuda()
+    out = {}
+    try:
+        for fuse in (True, False):
+            ag.FUSE_POSTNORM_BWD = fuse
+            xx, bb = x32.clone().requires_grad_(True), br.clone().requires_grad_(True)
+            gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            y32, y16 = ag.PostNormFn.apply(xx, bb, gm, bt, True, drops)
+            torch.autograd.backward([y32, y16] if two else [y32], [dy32, dy16] if two else [dy32])
+            out[fuse] = (xx.grad.clone(), bb.grad.clone(), gm.grad.clone(), bt.grad.clone())
+    finally:
+        ag.FUSE_POSTNORM_BWD = True
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    assert out[True][1].dtype == dtype and bool(torch.isfinite(out[True][1].float()).all())
+    if drops[0][0] > 0:      # the masks really are applied: dropped elements carry no gradient
+        assert float((out[True][1] == 0).float().mean()) >= 0.5 * drops[0][0]
+
+
 @pytest.mark.parametrize("c", __import__("oracle.make_golden_student", fromlist=["MLP_CASES"]).MLP_CASES, ids=lambda c: c["name"])
 def test_residual_mlp_vs_reference_class(golden, c):
     """HIP ResidualMLP against outputs + gradients of the reference class itself (models/student_model.py:8-35, compiled from

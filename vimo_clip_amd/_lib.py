@@ -49,6 +49,7 @@ SIGNATURES = {
     "vmc_layernorm_bwd_workspace_bytes": (Z, [I, I]),
     "vmc_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "vmc_layernorm_bwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "vmc_postnorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, F, ctypes.c_uint64, F, ctypes.c_uint64, I, P, Z, P]),
     "vmc_scale_by_device_scalar": (I, [P, P, Z, P, P]),
     "vmc_add": (I, [P, P, P, Z, I, I, I, I, P]),
     "vmc_mean_pool_bwd": (I, [P, P, I, I, I, I, I, I, P]),

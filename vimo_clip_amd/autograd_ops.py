@@ -142,6 +142,9 @@ def _grad_out(param, shape):
 # ------------------------------------------------------------------------------------------------
 # Linear
 # ------------------------------------------------------------------------------------------------
+FUSE_POSTNORM_BWD = True      # False: vmc_layernorm_bwd2 + vmc_cast_dropout2 (the two-pass path the fused launch is tested against)
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ res).  x [M,Kx] 16-bit (Kx = K or K padded to 64), W [N,K...] f32 parameter."""
 
@@ -382,11 +385,18 @@ class PostNormFn(torch.autograd.Function):
         dg, db = _grad_out(gamma, (D,)), _grad_out(beta, (D,))
         nbytes = lib.vmc_layernorm_bwd_workspace_bytes(rows, D)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=ssum.device)
+        (p1, s1), (p2, s2) = ctx.drops
+        dbr = torch.empty(dsum.shape, dtype=dt16, device=dsum.device)
+        if FUSE_POSTNORM_BWD:
+            # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds, cast to the branch's type -- from the LayerNorm
+            # backward's own store loop (vmc_postnorm_bwd) instead of a second pass over d sum
+            check(lib.vmc_postnorm_bwd(ptr(dy), ptr(dy2), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), ptr(dsum), ptr(dbr), ptr(dg),
+                                       ptr(db), rows, D, dt(dy), float(p1), int(s1), float(p2), int(s2), dt(dt16), ptr(ws), nbytes,
+                                       stream()), "postnorm_bwd")
+            return dsum, dbr, _deliver(gamma, dg), _deliver(beta, db), None, None
         check(lib.vmc_layernorm_bwd2(ptr(dy), ptr(dy2), ptr(ssum), ptr(gamma.detach()), ptr(mean), ptr(rstd), None, ptr(dsum), ptr(dg), ptr(db),
                                      rows, D, D, dt(dy), 0, 0, dt(dt16), ptr(ws), nbytes, stream()), "layernorm_bwd2")
-        (p1, s1), (p2, s2) = ctx.drops
-        if p1 > 0.0:        # d branch = d sum * mask1 (* mask2), masks regenerated from the seeds, cast to the branch's type: one pass
-            dbr = torch.empty(dsum.shape, dtype=dt16, device=dsum.device)
+        if p1 > 0.0:
             check(lib.vmc_cast_dropout2(ptr(dsum), ptr(dbr), dsum.numel(), float(p1), int(s1), float(p2), int(s2), dt(dt16), stream()),
                   "cast_dropout2")
         else:

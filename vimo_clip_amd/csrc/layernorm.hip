@@ -357,7 +357,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      const void* __restrict__ addp, float* __restrict__ partial, int rows,
-                                                     int D, size_t ldx, int dy_f32, int x_f32, int dx_f32) {
+                                                     int D, size_t ldx, int dy_f32, int x_f32, int dx_f32,
+                                                     uint16_t* __restrict__ dx16, float p1, uint64_t seed1_arg, float p2, uint64_t seed2_arg) {
+  // dx16 != NULL (vmc_postnorm_bwd): also the 16-bit gradient of the branch that was added in front of the LayerNorm, through the one
+  // or two dropouts the forward applied to it -- same masks (counter-based hash of the flat element index), same order of operations
+  // as vmc_cast_dropout2 on the stored dx, so the two paths agree bit for bit
+  const uint64_t seed1 = (dx16 && p1 > 0.f) ? resolve_seed(seed1_arg) : 0, seed2 = (dx16 && p2 > 0.f) ? resolve_seed(seed2_arg) : 0;
+  const uint32_t thr1 = (uint32_t)((double)p1 * 4294967296.0), thr2 = (uint32_t)((double)p2 * 4294967296.0);
+  const float sc1 = 1.0f / (1.0f - p1), sc2 = 1.0f / (1.0f - p2);
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 waves][2][D] floats
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
@@ -424,6 +431,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const void* __restrict__ dy
           o.x += ad[c].x; o.y += ad[c].y; o.z += ad[c].z; o.w += ad[c].w;
         }
         store4<T>(dx, (size_t)row * D + col, dx_f32, o);
+        if (dx16) {
+          const size_t e = (size_t)row * D + col;
+          float v[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (p1 > 0.f) v[j] = hash32(seed1, e + j) >= thr1 ? v[j] * sc1 : 0.0f;
+            if (p2 > 0.f) v[j] = hash32(seed2, e + j) >= thr2 ? v[j] * sc2 : 0.0f;
+          }
+          store4<T>(dx16, e, false, make_float4(v[0], v[1], v[2], v[3]));
+        }
       }
     }
   }
@@ -492,9 +509,31 @@ extern "C" int vmc_layernorm_bwd(const void* dy, const void* x, const float* gam
   return vmc_layernorm_bwd2(dy, nullptr, x, gamma, mean, rstd, add, dx, dgamma, dbeta, rows, D, ldx, dy_dtype, x_dtype, dx_dtype, dtype16,
                             workspace, workspace_bytes, stream);
 }
+static int ln_bwd_impl(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                       int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream,
+                       void* dx16, float p1, uint64_t seed1, float p2, uint64_t seed2);
 extern "C" int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
                                   int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
+  return ln_bwd_impl(dy, dy2, x, gamma, mean, rstd, add, dx, dgamma, dbeta, rows, D, ldx, dy_dtype, x_dtype, dx_dtype, dtype16, workspace,
+                     workspace_bytes, stream, nullptr, 0.f, 0, 0.f, 0);
+}
+// Backward of vmc_postnorm_dropout_fwd in one launch (+ the partial reduce): dsum (f32) = LN'(dy32 + dy16) on the saved pre-norm sum,
+// dbranch16 = dsum through the forward's dropout masks, cast -- what vmc_layernorm_bwd2 + vmc_cast_dropout2 (or a plain cast) did in
+// two passes over the gradient.
+extern "C" int vmc_postnorm_bwd(const void* dy, const void* dy2, const float* sum, const float* gamma, const float* mean, const float* rstd,
+                                float* dsum, void* dbranch16, float* dgamma, float* dbeta, int rows, int D, int dy_dtype, float p1,
+                                uint64_t seed1, float p2, uint64_t seed2, int dtype16, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dbranch16 || p1 < 0.f || p1 >= 1.f || p2 < 0.f || p2 >= 1.f || (p2 > 0.f && p1 <= 0.f)) return VMC_E_ARG;   // as the forward
+  if (((uintptr_t)dbranch16 | (uintptr_t)dsum) & 15) return VMC_E_ALIGN;
+  return ln_bwd_impl(dy, dy2, sum, gamma, mean, rstd, nullptr, dsum, dgamma, dbeta, rows, D, D, dy_dtype, VMC_F32, VMC_F32, dtype16, workspace,
+                     workspace_bytes, stream, dbranch16, p1, seed1, p2, seed2);
+}
+static int ln_bwd_impl(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, int ldx, int dy_dtype,
+                       int x_dtype, int dx_dtype, int dtype16, void* workspace, size_t workspace_bytes, void* stream,
+                       void* dx16, float p1, uint64_t seed1, float p2, uint64_t seed2) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return VMC_E_ARG;
   if (D % 4 || D > LN_BWD_MAX_CHUNKS * 256) return VMC_E_SHAPE;
   if (ldx % 4 || ldx < D) return VMC_E_ALIGN;
@@ -507,10 +546,12 @@ extern "C" int vmc_layernorm_bwd2(const void* dy, const void* dy2, const void* x
   do {                                                                                                                           \
     if (dtype16 == VMC_BF16)                                                                                                     \
       hipLaunchKernelGGL((ln_bwd_kernel<BF16, NCH>), dim3(grid), dim3(256), lds, s, dy, dy2, x, gamma, mean, rstd, dx, add,      \
-                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
+                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32,  \
+                         (uint16_t*)dx16, p1, seed1, p2, seed2);                                                                 \
     else                                                                                                                         \
       hipLaunchKernelGGL((ln_bwd_kernel<F16, NCH>), dim3(grid), dim3(256), lds, s, dy, dy2, x, gamma, mean, rstd, dx, add,       \
-                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32); \
+                         (float*)workspace, rows, D, (size_t)ldx, dy_dtype == VMC_F32, x_dtype == VMC_F32, dx_dtype == VMC_F32,  \
+                         (uint16_t*)dx16, p1, seed1, p2, seed2);                                                                 \
   } while (0)
   if (D <= 512) VMC_LN_BWD(2);
   else if (D <= 768) VMC_LN_BWD(3);
