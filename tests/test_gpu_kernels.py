@@ -31,6 +31,7 @@ def _ints(shape, lo, hi, seed):
     (65792 // 16, 1024, 1024),                 # 4112 rows: 128x128 config with a ragged last row tile
     (3333, 4096, 128), (3100, 3072, 64),       # 256x256 tiles (>= 192): 8-phase kernel (K % 128 == 0) / two-stage kernel
     (16448, 1024, 1024), (3333, 4100, 256), (65792, 1024, 128),   # 8-phase: many K tiles, ragged N, the ViT-L/14 row count
+    (4100, 2304, 256), (8224, 1024, 128),      # 129 .. 191 tiles of 256x256 with more than 512 tiles of 128x128: one 8-phase round
     (300, 140, 64), (50, 768, 192), (8, 384, 768), (129, 2304, 768), (1000, 64, 3072), (16448, 256, 640),
 ])
 def test_linear_exact_integers(ops, dtype, M, N, K):

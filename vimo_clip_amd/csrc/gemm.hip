@@ -373,7 +373,12 @@ static int linear_impl(const void* A, const void* W, const float* bias, const vo
   // variant VMC_GEMM_TWOSTAGE forces the two-stage kernels (A/B measurements through vmc_linear_variant).
   g.variant = variant;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (variant != VMC_GEMM_TWOSTAGE && t256 >= 192 && (K % 128) == 0) {
+  // Between 129 and 191 tiles of 256x256 the 128x128 kernel would need a second round of its 512 resident workgroups (t128 > 512)
+  // while the 8-phase kernel still finishes in one: M = 4096, N = 2304, K = 768 (TFAM qkv at 256 clips) 31.6 -> 21.2 us; at <= 128
+  // tiles the two are equal (20.8 / 20.0 us at 96 tiles) and below 96 the small tiles win (profiles/README.md, round 2).
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool big = t256 >= 192 || (t256 > 128 && t128 > 512);
+  if (variant != VMC_GEMM_TWOSTAGE && big && (K % 128) == 0) {
     // Round quantisation: T tiles on 256 CUs cost ceil(T/256) tile-times.  When the last, partial round holds only a few
     // tiles (ViT-L/14: 257 x tn tiles -> tn tiles in a round of their own: +25 % at tn = 4; student ViT-B/32: 100 x 3 tiles ->
     // 44 tiles in a second round), the tile rows that do not fit the full rounds go to the small-tile kernels, which spread
