@@ -404,6 +404,28 @@ def tfam_small_batch_train(dev, cdt, m, batches=(8, 64, 512), iters=30):
     return res
 
 
+def tfam_cpu_baseline(ncpu: int, batches=(8, 64), reps: int = 3) -> dict:
+    """the CPU restatement of the TFAM forward (oracle/tfam.py, fp32 PyTorch) timed on the host cores at B = 8 and B = 64,
+    the geometry of the `tfam_forward` block (768 / 8 heads / 4 layers / ff 2048 / 140 classes, 16 + 16 tokens).  Checker code, timed
+    beside the GPU figures as a reported baseline only."""
+    from oracle import tfam as otfam
+    from vimo_clip_amd import synth
+    torch.set_num_threads(ncpu)
+    sd = synth.tfam_state_dict(768, 8, 4, 2048, 140, 4)
+    out = {"cores": ncpu, "kind": "port", "unit": "clips/s"}
+    with torch.no_grad():
+        for B in batches:
+            rgb, mot = synth.normal(10, "rgb", (B, 16, 768)), synth.normal(10, "mot", (B, 16, 768))
+            mk = torch.ones(B, 16, dtype=torch.bool)
+            otfam.amo_clip_forward(sd, rgb, mot, mk, mk, nhead=8)      # warm-up
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                otfam.amo_clip_forward(sd, rgb, mot, mk, mk, nhead=8)
+            out[f"B{B}"] = round(B * reps / (time.perf_counter() - t0), 1)
+    out["sample"] = f"oracle/tfam.py fp32 PyTorch CPU, {reps} forwards per batch size"
+    return out
+
+
 def selftest_spawn(rank: int, world: int) -> None:
     """CPU rehearsal of the N-rank control flow (tests/test_bench_spawn.py): gloo rendezvous from the spawned environment,
     one all-reduce, rank 0 prints a line in the bench format.  No GPU is touched."""
@@ -652,6 +674,11 @@ def main():
                     dt_cpu = time.perf_counter() - t1
                 result["cpu_baseline"] = {"value": round(nf / dt_cpu, 3), "unit": "frame-embeddings/s", "cores": ncpu, "kind": "port",
                                           "sample": f"oracle/vit.py fp32 PyTorch CPU, {nf} frames of the same workload, 1 pass"}
+                if not args.no_extras:
+                    try:
+                        result["cpu_baseline"]["tfam_forward"] = tfam_cpu_baseline(ncpu)
+                    except Exception as e:      # noqa: BLE001
+                        result["cpu_baseline"]["tfam_forward"] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:      # noqa: BLE001
             result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(result), flush=True)
