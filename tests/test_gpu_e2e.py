@@ -331,3 +331,60 @@ def test_trainer_with_captured_steps_follows_the_uncaptured_trainer():
     for k in we:
         d = (we[k].float() - wg[k].float()).abs().max().item()
         assert d <= 5e-3 * max(1e-3, we[k].float().abs().max().item()), (k, d)
+
+
+def test_fused_eval_sees_the_weights_of_replayed_training_steps():
+    """with captured training steps the optimiser and the 16-bit copy refresh run INSIDE graph replays; the
+    fused evaluation chain (d_model 512, fixed T = 16: the shapes tfam_fused.supported() accepts) must still see the current
+    weights.  Epochs 2 and 3 are pure replays of the one graph captured in epoch 1; after each epoch validate() through the
+    fused chain must equal validate() through the per-op path (which reads the in-place refreshed copies) and must have moved."""
+    from vimo_clip_amd import tfam_fused
+    from vimo_clip_amd.TFAM.data.dataset import SyntheticEmbeddingDataset
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    from vimo_clip_amd.TFAM.train_and_eval import Config, ModelTrainer
+    D, H, L, FF, C, BS = 512, 8, 2, 512, 140, 8
+    tr = SyntheticEmbeddingDataset(_labels("train", 64), D, tmin=16, tmax=16, seed=5, signal=0.6)
+    va = SyntheticEmbeddingDataset(_labels("val", 32), D, tmin=16, tmax=16, seed=6, signal=0.6)
+    cfg = Config(epochs=3, batch_size=BS, d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, dropout=0.0, mlp_dropout=0.0,
+                 device="cuda", checkpoint_dir=None, use_graphs=True)
+    model = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda()
+    model.load_state_dict(synth.tfam_state_dict(D, H, L, FF, C, 78), strict=True)
+    assert tfam_fused.supported(model, BS, 16, 15, True)
+    t = ModelTrainer(model, tr, va, cfg)
+    prev = None
+    for ep in range(3):
+        t.train_epoch(ep)
+        assert len(t._graphed_train._graphs) == 1                 # epochs 2, 3: replays only
+        model.fused_inference = True
+        fused = t.validate(ep)
+        model.fused_inference = False
+        perop = t.validate(ep)
+        model.fused_inference = True
+        print("epoch", ep, "fused", fused, "per-op", perop)
+        assert abs(fused[0] - perop[0]) <= 2e-3 * max(abs(perop[0]), 1e-3) and abs(fused[1] - perop[1]) <= 2e-3, (ep, fused, perop)
+        assert prev is None or abs(fused[0] - prev) > 1e-4, "validation loss did not move: stale weights"
+        prev = fused[0]
+        t.scheduler.step()
+
+
+def test_fused_scratch_of_captured_forwards_is_never_freed():
+    """TfamPack.workspace() used to clear every scratch buffer once 17 shapes had been seen, although live
+    hipGraphs had their addresses baked in.  Scratch that a capture used is pinned; only eager-only scratch is evicted."""
+    from vimo_clip_amd import tfam_fused
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    D, H, L, FF, C = 512, 8, 1, 512, 10
+    model = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, device="cuda").cuda().eval()
+    pack = tfam_fused.get_pack(model, torch.bfloat16).refresh()
+    ws0 = pack.workspace(2, 16, 15, True, 0)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pass
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        assert pack.workspace(2, 16, 15, True, 0).data_ptr() == ws0.data_ptr()
+    for T in range(1, 31):                                        # 30 more eager shapes
+        pack.workspace(2, T, 15, True, 1)
+    assert pack.workspace(2, 16, 15, True, 0).data_ptr() == ws0.data_ptr()
+    assert (2, 16, 15, True, 0) in pack._pinned and len(pack._ws) <= pack.MAX_UNPINNED + 1

@@ -33,6 +33,26 @@ def _worker(rank, world, port, q):
         want[0::7] += 0.5
         want[1::7] += 0.5
         assert scale == 0.5 and torch.equal(flat, want)
+        # ---- the two exchange algorithms: reduce-scatter + all-gather == all-reduce, bit for bit ----
+        gen = torch.Generator().manual_seed(1234 + rank)
+        base = torch.randn(70_000, generator=gen)               # 70 000 = 4 buckets of 16 384 + a ragged bucket of 4 464 (even: shards)
+        odd = torch.randn(16_385, generator=gen)                # last bucket of 1 element: not divisible by world -> all-reduce fallback
+        for src in (base, odd):
+            outs = {}
+            for ex in parallel.GradientAllReducer.EXCHANGES:
+                buf = src.clone()
+                r = parallel.GradientAllReducer(buf, bucket_bytes=64 * 1024, exchange=ex)
+                assert r.exchange == ex and r.all_reduce() == 0.5
+                outs[ex] = buf
+            assert torch.equal(outs["all_reduce"], outs["rs_ag"])
+            both = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(both, src)
+            assert torch.equal(outs["rs_ag"], both[0] + both[1])
+        try:
+            parallel.GradientAllReducer(base.clone(), exchange="ring")
+            raise AssertionError("bad exchange name accepted")
+        except ValueError:
+            pass
         # ---- bucket launches overlapped with the backward (attach): reports arrive in reverse parameter order ----
         class _P:                                            # stand-in for a parameter: only numel() and identity matter
             def __init__(self, n):

@@ -303,6 +303,8 @@ class ModelTester:
         """:186-191 — weights-only load of ``best_model.pth`` (keys with or without the DataParallel ``module.`` prefix)."""
         from ..checkpoint import load_state_dict
         load_state_dict(self.model, os.path.join(checkpoint_dir, "best_model.pth"))
+        from .. import autograd_ops
+        autograd_ops.weights.clear()      # new masters: cached 16-bit copies, weight packs and captured forwards are stale (bumps the epoch)
         self.model.eval()
         return self
 
@@ -369,15 +371,26 @@ def run(cfg, rank=0, world=1, limit=2048, train_annotations=None, val_annotation
     model = build_model(cfg)
     model.set_dropout_seed(cfg.seed * 1000 + rank)
     out = {"world": world, "task": cfg.task}
+    wrote_best = False
     if cfg.mode in ("train", "both"):
-        out["best_val_metric"] = ModelTrainer(model, train_set, val_set, cfg, rank, world).train()
+        trainer = ModelTrainer(model, train_set, val_set, cfg, rank, world)
+        out["best_val_metric"] = trainer.train()
+        # rank 0 writes best_model.pth exactly when the validation metric improved during THIS run (save_checkpoint)
+        wrote_best = bool(getattr(cfg, "checkpoint_dir", None)) and trainer.best_val_mAP > 0.0
     if cfg.mode in ("test", "both"):
         tester = ModelTester(model, val_set, cfg, rank, world)
         best = os.path.join(cfg.checkpoint_dir, "best_model.pth") if getattr(cfg, "checkpoint_dir", None) else None
-        if best and os.path.exists(best):              # :404-406: the tester evaluates the best checkpoint, not the last epoch
-            if world > 1:
-                import torch.distributed as dist
-                dist.barrier()                          # rank 0 has finished writing it
+        # every rank must take the same branch.  Rank 0 decides (after training: "did this run write the file";
+        # a best_model.pth left behind by an earlier run is NOT picked up silently; test-only mode: "does the file exist"),
+        # the decision is broadcast, and the barrier that orders rank 0's write before the other ranks' reads is unconditional.
+        have = wrote_best if cfg.mode == "both" else bool(best and os.path.exists(best))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()                              # rank 0 has finished writing it
+            flag = [have]
+            dist.broadcast_object_list(flag, src=0)
+            have = bool(flag[0])
+        if have:                                        # :404-406: the tester evaluates the best checkpoint, not the last epoch
             tester.load_best_model(cfg.checkpoint_dir)
         elif cfg.mode == "test":
             raise FileNotFoundError(f"mode='test' needs {best or '<checkpoint_dir>/best_model.pth'} (TFAM/train_and_eval.py:404-406)")

@@ -5,7 +5,9 @@
   back into a DataParallel-wrapped model ``strict=True``.
 * TFAM: ``{"epoch", "state_dict", "optimizer", "scheduler", "best_val_loss", "best_val_mAP"}`` written as
   ``best_model.pth`` only when the validation mAP improves (TFAM/train_and_eval.py:133-148), reloaded before testing
-  (:186-191).
+  (:186-191).  The ``"optimizer"`` entry is ``FusedAdam.state_dict()`` = ``{"step", "m", "v", "lr"}`` over the flat parameter
+  arena, NOT ``torch.optim.AdamW.state_dict()``'s per-parameter layout: the reference's loaders only read ``state_dict``
+  (:188-190), so weights interchange and optimiser state does not.
 
 Files written here keep the ``module.`` prefix (so the reference's own loaders accept them); loading accepts both forms.
 Reference files are opened with ``weights_only=True`` (nothing in the file is executed).  ``state_dict()`` tensors of a

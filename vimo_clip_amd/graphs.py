@@ -76,4 +76,9 @@ class GraphedTrainStep:
             g = self._graphs[key] = self._capture(inputs)
         out = g(*inputs)
         self.opt.step_count += 1                               # host mirror of the device step count
+        # host mirror of what the replayed Adam + vmc_cast_weights_multi launches did: the masters and their 16-bit copies
+        # changed without any Python running, so everything keyed on the weight epoch (TfamPack.pack_is_current, captured
+        # evaluation forwards) must see a new epoch (the fused eval path scored stale packs after pure replays)
+        from . import autograd_ops
+        autograd_ops.weights.epoch += 1
         return out

@@ -139,10 +139,15 @@ class FusedAdam:
         return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
 
     def load_state_dict(self, sd):
+        """Layout {step, m, v, lr} over the flat arena (NOT torch.optim's per-parameter state: checkpoint.py says so)."""
         self.step_count = int(sd["step"])
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.param_groups[0]["lr"] = sd["lr"]
+        if getattr(self, "dev_state", None) is not None:      # device-state mode: the step count and lr the kernels read
+            self.dev_state[0] = self.step_count
+            self._hyper_host = None
+            self.sync_hyper()
 
 
 def invalidate_weight_copies(optimizer=None):

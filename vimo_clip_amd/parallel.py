@@ -58,7 +58,19 @@ class GradientAllReducer:
     runs un-overlapped; parameters that never report (unused in the fusion mode) are flushed by ``all_reduce()``.  Every rank
     runs the same graph, so the launch order of the collectives is the same on every rank."""
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 48 << 20):
+    EXCHANGES = ("all_reduce", "rs_ag")
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 48 << 20, exchange: str | None = None):
+        """exchange: "all_reduce" (one collective per bucket; RCCL picks ring or tree) or "rs_ag" (reduce_scatter_tensor into a
+        1/world shard, then all_gather_into_tensor back into the bucket: on the fully connected 8-GPU xGMI mesh both halves are
+        direct exchanges that keep all seven links of a GPU busy, where a ring is bound by one link -- SURVEY.md 8e).  Default:
+        the VMC_GRAD_EXCHANGE environment variable, else "all_reduce".  The sums are the same numbers in both; their
+        association order may differ for world > 2."""
+        exchange = exchange or os.environ.get("VMC_GRAD_EXCHANGE", "all_reduce")
+        if exchange not in self.EXCHANGES:
+            raise ValueError(f"GradientAllReducer: exchange must be one of {self.EXCHANGES}, got {exchange!r}")
+        self.exchange = exchange
+        self._shards = {}
         self.flat = flat_grad
         n = max(64, bucket_bytes // flat_grad.element_size())
         self.bucket_elems = n
@@ -91,9 +103,22 @@ class GradientAllReducer:
             autograd_ops.grad_ready_hooks.remove(self.on_grad_ready)
         self._attached = False
 
+    def _issue(self, b):
+        """Start the exchange of bucket b; returns what finish() must complete."""
+        buf, world = self.buckets[b], world_size()
+        if self.exchange == "all_reduce" or buf.numel() % world:      # a ragged bucket cannot be cut into equal shards
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        shard = self._shards.get(b)
+        if shard is None or shard.numel() != buf.numel() // world:
+            shard = self._shards[b] = torch.empty(buf.numel() // world, dtype=buf.dtype, device=buf.device)
+        rs = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, async_op=True)
+        if dist.get_backend() == "nccl":            # RCCL runs a group's collectives in issue order on its own stream
+            return dist.all_gather_into_tensor(buf, shard, async_op=True)
+        return (rs, buf, shard)                     # gloo's worker threads give no such order: the gather is issued in finish()
+
     def _launch(self, b):
         self._launched[b] = True
-        self._pending.append(dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append(self._issue(b))
 
     def on_grad_ready(self, param):
         k = id(param)
@@ -121,7 +146,7 @@ class GradientAllReducer:
         if world_size() == 1:
             return
         if not self._attached:
-            self._pending = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in self.buckets]
+            self._pending = [self._issue(b) for b in range(len(self.buckets))]
             return
         self._n_early = sum(self._launched)
         if self._expected is None:                  # first step: learn the report counts, reduce everything now
@@ -133,7 +158,14 @@ class GradientAllReducer:
 
     def finish(self) -> float:
         """Wait for the buckets; returns the factor the optimiser must scale gradients by (1/world)."""
+        gathers = []
         for w in self._pending:
+            if isinstance(w, tuple):                # (reduce-scatter work, bucket, shard): second half of an rs_ag exchange
+                w[0].wait()
+                gathers.append(dist.all_gather_into_tensor(w[1], w[2], async_op=True))
+            else:
+                w.wait()
+        for w in gathers:
             w.wait()
         self._pending = []
         if self._attached and self._expected is not None:

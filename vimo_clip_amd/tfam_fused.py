@@ -42,6 +42,8 @@ def supported(model, B, T, Tk, has_cross) -> bool:
 
 
 class TfamPack:
+    MAX_UNPINNED = 16       # scratch buffers of eager forwards kept around (each a few MB)
+
     def __init__(self, model, dtype16):
         self.model, self.dtype16 = model, dtype16
         self.D, self.H, self.L = model.d_model, model.nhead, len(model.layers)
@@ -52,6 +54,7 @@ class TfamPack:
         self.ppack = torch.zeros(self._off(P_END, 0), dtype=torch.float32, device=dev)
         self._key = None
         self._ws = {}
+        self._pinned = set()
 
     def _off(self, slot, layer):
         off = lib.vmc_tfam_pack_offset(slot, layer, self.D, self.ff, self.L, self.C)
@@ -133,11 +136,21 @@ class TfamPack:
         independent batches) need a scratch buffer each."""
         key = (B, T, Tk, has_cross, slot)
         ws = self._ws.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if ws is None:
+            if capturing:
+                raise RuntimeError("TfamPack.workspace: scratch must exist before a capture (GraphedCallable's warm-up allocates it)")
             n = lib.vmc_tfam_workspace_bytes(B, T, Tk, self.D, self.ff, self.L, self.C, int(has_cross))
-            if len(self._ws) > 16:
-                self._ws.clear()
+            if len(self._ws) >= self.MAX_UNPINNED + len(self._pinned):
+                # only scratch that no hipGraph has baked into its launches may be dropped (ADVICE r2: clearing everything freed
+                # buffers live graphs still wrote to); the oldest unpinned entry goes
+                for k in list(self._ws):
+                    if k not in self._pinned:
+                        del self._ws[k]
+                        break
             ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.wpack.device)
+        if capturing:
+            self._pinned.add(key)                      # its address is now part of a graph: never freed while this pack lives
         return ws
 
     def forward(self, x, motion, mask, mask_kv, has_cross, slot=0):
