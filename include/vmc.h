@@ -381,6 +381,79 @@ int vmc_tfam_forward(const float* x, const float* motion, const uint8_t* mask, c
                      int D, int H, int ff, int L, int C, int has_cross, int dtype16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K11-K14 fused, TRAINING — forward + backward of the TFAM block for short clips as two launch chains
+ * (TFAM/models/AMO_CLIP.py:37-51,99-171 in train mode under TFAM/train_and_eval.py:66-101: `output = model(...)`,
+ * `loss.backward()`).  Same shape set as the eval chain above.
+ *
+ * Forward: the six launches per layer of the eval chain with the training arithmetic added in place -- LayerNorm with its
+ * affine part in the GEMM prologue (unfolded weights), dropout on the attention probabilities inside the attention
+ * prologue, the branch dropouts (AMO_CLIP.py:40,45,50 and ffn's own nn.Dropout :27-28) inside the GEMM epilogues -- and the
+ * tensors the backward needs written as side outputs (16-bit GEMM operands, pre-norm sums, keep masks, lse).
+ * Backward, per layer (8 launches + 1): LayerNorm backward in the PROLOGUE of the dgrad GEMM that consumes the branch
+ * gradient (three times), the two dgrad GEMMs with the residual gradient added in the epilogue, vmc_attention_bwd twice,
+ * the qkv dgrad, and ONE grouped launch for all seven weight gradients, their bias gradients and the three LayerNorms'
+ * parameter gradients.  Gradients are WRITTEN (not accumulated) through the pointers below; NULL = not wanted.
+ *
+ * Parameters are passed as structs of device pointers (no packing, nothing copied): 16-bit compute copies [N, K] and their
+ * transposes [K, N] (what vmc_cast_weights_multi keeps current after every optimiser step), fp32 masters for biases and
+ * LayerNorm parameters, fp32 gradient destinations (e.g. views into a flat gradient arena).
+ *   w_cross_in = cross_attn.in_proj_weight [3D, D] (q rows 0:D, k|v rows D:3D), wt_cross_in its transpose [D, 3D].
+ *
+ * Dropout: p_drop (AttentionLayer's dropout: attention probabilities, the three branch dropouts, the FFN's two), p_mlp
+ * (classifier.3).  seeds[7*L + 1] host array, each a value or (bit 63) a device address (include "seed arguments"): per layer
+ * {self-attn P, self branch, cross-attn P, cross branch, FFN inner, FFN trailing, FFN branch}, then the classifier's.
+ * The element index of every mask equals the per-op path's (vmc_dropout on the [M, N] tensor; vmc_attention_fwd's
+ * (b, h, q, k)), so both paths draw identical masks from identical seeds.  The backward must be given the same values.
+ */
+typedef struct vmc_tfam_layer_params {
+  const void *w_self_in, *w_self_out, *w_cross_in, *w_cross_out, *w_ffn0, *w_ffn3;          /* 16-bit [N, K] */
+  const void *wt_self_in, *wt_self_out, *wt_cross_in, *wt_cross_out, *wt_ffn0, *wt_ffn3;    /* 16-bit [K, N] */
+  const float *b_self_in, *b_self_out, *b_cross_in, *b_cross_out, *b_ffn0, *b_ffn3;
+  const float *ln_self_g, *ln_self_b, *ln_cross_g, *ln_cross_b, *ln_ffn_g, *ln_ffn_b;
+  float *gw_self_in, *gw_self_out, *gw_cross_in, *gw_cross_out, *gw_ffn0, *gw_ffn3;
+  float *gb_self_in, *gb_self_out, *gb_cross_in, *gb_cross_out, *gb_ffn0, *gb_ffn3;
+  float *g_ln_self_g, *g_ln_self_b, *g_ln_cross_g, *g_ln_cross_b, *g_ln_ffn_g, *g_ln_ffn_b;
+} vmc_tfam_layer_params;
+typedef struct vmc_tfam_head_params {
+  const void *w_cls1, *w_cls4;                   /* 16-bit classifier.1.weight [D/2, D], classifier.4.weight [C, D/2] */
+  const float *w32_cls1, *w32_cls4;              /* their fp32 masters (the head's backward is 8..16 rows of work: fp32 FMAs) */
+  const float *cls_ln_g, *cls_ln_b, *b_cls1, *b_cls4;
+  float *g_cls_ln_g, *g_cls_ln_b, *gw_cls1, *gb_cls1, *gw_cls4, *gb_cls4;
+} vmc_tfam_head_params;
+/* Saved activations + backward scratch of one step of B clips; caller-owned, must stay untouched between fwd and bwd. */
+size_t vmc_tfam_train_workspace_bytes(int B, int T, int Tk, int D, int H, int ff, int L, int C, int has_cross);
+/* AttentionLayer.forward in train mode.  layers = all L structs (layer l > 0 reads layer l-1's norm_ffn);  x_in: the fp32 tokens
+ * (layer 0; NULL otherwise); motion: raw fp32 motion tokens [B*Tk, D] (has_cross).  seeds: the 7 seeds of THIS layer. */
+int vmc_tfam_layer_train_fwd(const float* x_in, const float* motion, const uint8_t* mask, const uint8_t* mask_kv,
+                             const vmc_tfam_layer_params* layers, int layer, void* workspace, size_t workspace_bytes,
+                             int B, int T, int Tk, int D, int H, int ff, int L, int C, int has_cross, float p_drop,
+                             const uint64_t* seeds, int dtype16, void* stream);
+/* mean-pool + classifier in train mode (AMO_CLIP.py:84,:170), logits fp32 [B, C]. */
+int vmc_tfam_head_train_fwd(const vmc_tfam_layer_params* layers, const vmc_tfam_head_params* head, float* logits,
+                            void* workspace, size_t workspace_bytes, int B, int T, int Tk, int D, int H, int ff, int L, int C,
+                            int has_cross, float p_mlp, uint64_t seed, int dtype16, void* stream);
+/* Backward of the head: from dlogits fp32 [B, C] to the gradient wrt the last layer's output (left in the workspace) and
+ * the classifier's parameter gradients (autograd of AMO_CLIP.py:170-171). */
+int vmc_tfam_head_bwd(const float* dlogits, const vmc_tfam_layer_params* layers, const vmc_tfam_head_params* head,
+                      void* workspace, size_t workspace_bytes, int B, int T, int Tk, int D, int H, int ff, int L, int C,
+                      int has_cross, float p_mlp, uint64_t seed, int dtype16, void* stream);
+/* Backward of one AttentionLayer (autograd of AMO_CLIP.py:37-51): consumes the gradient wrt its output from the workspace,
+ * leaves the gradient wrt its input there for layer-1 (not computed for layer 0: the tokens need no gradient), writes the
+ * layer's parameter gradients.  x_in (layer 0 only) is not read: its 16-bit cast was saved by the forward. */
+int vmc_tfam_layer_bwd(const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_layer_params* layers, int layer,
+                       void* workspace, size_t workspace_bytes, int B, int T, int Tk, int D, int H, int ff, int L, int C,
+                       int has_cross, float p_drop, const uint64_t* seeds, int dtype16, void* stream);
+/* Whole chains: L x layer_train_fwd + head_train_fwd; head_bwd + L x layer_bwd (last layer first). */
+int vmc_tfam_train_fwd(const float* x, const float* motion, const uint8_t* mask, const uint8_t* mask_kv,
+                       const vmc_tfam_layer_params* layers, const vmc_tfam_head_params* head, float* logits, void* workspace,
+                       size_t workspace_bytes, int B, int T, int Tk, int D, int H, int ff, int L, int C, int has_cross,
+                       float p_drop, float p_mlp, const uint64_t* seeds, int dtype16, void* stream);
+int vmc_tfam_train_bwd(const float* dlogits, const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_layer_params* layers,
+                       const vmc_tfam_head_params* head, void* workspace, size_t workspace_bytes, int B, int T, int Tk, int D,
+                       int H, int ff, int L, int C, int has_cross, float p_drop, float p_mlp,
+                       const uint64_t* seeds, int dtype16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K15 — fused Adam / AdamW over one flat fp32 buffer (train.py:66; TFAM/train_and_eval.py:53).
  *   decoupled_wd = 1: p *= 1 - lr*wd first (AdamW); 0: g += wd*p (Adam L2).
  *   grad_scale multiplies g first (clip_grad_norm_ coefficient / DDP averaging).

@@ -168,6 +168,10 @@ class _CrossAttn(torch.autograd.Function):
         return dq, dkv, None, None, None, None, None, None, None
 
 
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
 def _mask_u8(mask, dev):
     """[B,T] mask (True / 1 = real token) as a uint8 device tensor.  torch.bool is one byte holding 0 / 1: it is VIEWED, not
     cast (a cast is one more kernel launch per mask per forward, 8 us of a 210 us forward at the reference batch)."""
@@ -196,6 +200,7 @@ class AMO_CLIP(nn.Module):
                                         _linear_init(_Lin(d_model // 2, num_classes)))
         self.projection_layer = _linear_init(_Lin(2 * d_model, d_model))
         self.fused_inference = True     # eval + no_grad forwards of short clips run the fused launch chain (tfam_fused.py)
+        self.fused_training = True      # train-mode forwards of short clips run the fused training chains (tfam_train.py)
         self.set_dropout_seed(0x5EED)
 
     def set_dropout_seed(self, seed: int):
@@ -237,15 +242,12 @@ class AMO_CLIP(nn.Module):
                 out.append(p)
         return out
 
-    def _forward_fused(self, rgb_emb, motion_emb, m_rgb, m_flow):
-        """Eval forward through vmc_tfam_forward (one call: hoisted K|V GEMM + 6 launches per layer + pool + head).
-        Returns None when the shapes are outside the fused chain's set; the per-op path below then runs."""
+    def _fused_inputs(self, rgb_emb, motion_emb, m_rgb, m_flow, training):
+        """(x, mask, motion, mask_kv, cross) of the fused chains for the configured fusion mode, or None when the mode / shapes are
+        outside their set (the per-op path then runs)."""
         from ... import tfam_fused as tf
+        from ... import tfam_train as tt
         dt16 = self.compute_dtype
-
-        def f32(t):
-            return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
-
         motion, m_kv, cross = None, None, False
         if self.use_only_rgb:
             x, m = rgb_emb, m_rgb
@@ -260,16 +262,39 @@ class AMO_CLIP(nn.Module):
                 x = torch.cat([rgb_cut, motion_emb], dim=1)                   # token concat: memory plumbing
                 m = torch.cat([m_cut, m_flow], dim=1).contiguous() if m_cut is not None else None
             else:
+                if training:                          # the projection layer's gradient needs d(tokens): per-op path
+                    return None
                 xcat = torch.cat([rgb_cut, motion_emb], dim=-1)
                 if not tf.supported(self, xcat.shape[0], xcat.shape[1], 0, False):
                     return None
-                x = ag.linear(ag.cast(f32(xcat).view(-1, xcat.shape[-1]), dt16), self.projection_layer.weight,
+                x = ag.linear(ag.cast(_f32c(xcat).view(-1, xcat.shape[-1]), dt16), self.projection_layer.weight,
                               self.projection_layer.bias, out_f32=True).view(xcat.shape[0], xcat.shape[1], -1)
                 m = m_flow
-        if x.shape[-1] != self.d_model or not tf.supported(self, x.shape[0], x.shape[1], motion.shape[1] if cross else 0, cross):
+        ok = tt.supported if training else tf.supported
+        if x.shape[-1] != self.d_model or not ok(self, x.shape[0], x.shape[1], motion.shape[1] if cross else 0, cross):
             return None
-        pack = tf.get_pack(self, dt16).refresh()
-        return pack.forward(f32(x), f32(motion) if cross else None, m, m_kv, cross, slot=getattr(self, "fused_slot", 0))
+        return _f32c(x), m, (_f32c(motion) if cross else None), m_kv, cross
+
+    def _forward_fused(self, rgb_emb, motion_emb, m_rgb, m_flow):
+        """Eval forward through vmc_tfam_forward (one call: hoisted K|V GEMM + 6 launches per layer + pool + head).
+        Returns None when the shapes are outside the fused chain's set; the per-op path below then runs."""
+        from ... import tfam_fused as tf
+        sel = self._fused_inputs(rgb_emb, motion_emb, m_rgb, m_flow, False)
+        if sel is None:
+            return None
+        x, m, motion, m_kv, cross = sel
+        pack = tf.get_pack(self, self.compute_dtype).refresh()
+        return pack.forward(x, motion, m, m_kv, cross, slot=getattr(self, "fused_slot", 0))
+
+    def _forward_fused_train(self, rgb_emb, motion_emb, m_rgb, m_flow):
+        """Train-mode forward + (through autograd) backward as the fused launch chains of tfam_train.py: one autograd node for the
+        whole model.  None when the mode / shapes are outside the chain's set."""
+        from ... import tfam_train as tt
+        sel = self._fused_inputs(rgb_emb, motion_emb, m_rgb, m_flow, True)
+        if sel is None:
+            return None
+        x, m, motion, m_kv, cross = sel
+        return tt.forward_train(self, x, motion, m, m_kv, cross, self._next_seed)
 
     def forward(self, rgb_emb, motion_emb, mask_rgb=None, mask_flow=None):
         dt16, D = self.compute_dtype, self.d_model
@@ -287,6 +312,11 @@ class AMO_CLIP(nn.Module):
             out = self._forward_fused(rgb_emb, motion_emb, m_rgb, m_flow)
             if out is not None:
                 return out
+        if self.fused_training and self.training and torch.is_grad_enabled():
+            out = self._forward_fused_train(rgb_emb, motion_emb, m_rgb, m_flow)
+            if out is not None:
+                return out
+            self._seed_site = -1                          # nothing was drawn on a path that declined
 
         def flat(t):
             return t.contiguous().float().view(-1, t.shape[-1])

@@ -80,6 +80,13 @@ SIGNATURES = {
     "vmc_tfam_layer_fwd": (I, [P, P, P, P, P, I, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
     "vmc_tfam_head_fwd": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
     "vmc_tfam_forward": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, I, I, I, P]),
+    "vmc_tfam_train_workspace_bytes": (Z, [I] * 9),
+    "vmc_tfam_layer_train_fwd": (I, [P, P, P, P, P, I, P, Z] + [I] * 9 + [F, P, I, P]),
+    "vmc_tfam_head_train_fwd": (I, [P, P, P, P, Z] + [I] * 9 + [F, ctypes.c_uint64, I, P]),
+    "vmc_tfam_head_bwd": (I, [P, P, P, P, Z] + [I] * 9 + [F, ctypes.c_uint64, I, P]),
+    "vmc_tfam_layer_bwd": (I, [P, P, P, I, P, Z] + [I] * 9 + [F, P, I, P]),
+    "vmc_tfam_train_fwd": (I, [P, P, P, P, P, P, P, P, Z] + [I] * 9 + [F, F, P, I, P]),
+    "vmc_tfam_train_bwd": (I, [P, P, P, P, P, P, Z] + [I] * 9 + [F, F, P, I, P]),
     "vmc_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, I, F, P]),
     "vmc_train_tick": (I, [P, P, F, F, I, P]),
     "vmc_adam_step_dev": (I, [P, P, P, P, Z, P, F, F, F, F, I, P]),

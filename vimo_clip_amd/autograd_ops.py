@@ -31,6 +31,7 @@ class _WeightCache:
         self._tables = {}       # dtype16 -> (key, device descriptor table, n, tiles) of refresh()
         self._old_tables = []
         self.epoch = 0          # bumped whenever the masters may have changed behind autograd's version counters
+        self.generation = 0     # bumped when copies are DROPPED (their buffers may be freed): pointer tables built from them are void
 
     def get(self, p: torch.Tensor, dtype16, transposed=False, pad_k=False, both=False):
         if not isinstance(p, torch.nn.Parameter):      # temporaries (e.g. row slices of in_proj_weight) are not cached
@@ -56,6 +57,7 @@ class _WeightCache:
         self._c.clear()
         self._tables.clear()
         self.epoch += 1
+        self.generation += 1
 
     def refresh(self, owner=None, param_ids=None):
         """The optimiser kernel rewrote the fp32 masters in place: re-cast every cached copy of the trained parameters into its

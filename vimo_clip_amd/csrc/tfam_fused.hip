@@ -29,815 +29,7 @@
 //
 // Supported: T, Tk <= 32, d_model in {512, 768}, head_dim in {64, 96}, (clips per block) * nhead a multiple of 4.
 // Everything else returns VMC_E_SHAPE and the caller uses the general per-op path.
-#include "common.h"
-
-namespace {
-
-constexpr int TF_BM = 32;
-constexpr int TF_NTH = 256;
-
-enum { PRO_F32 = 0, PRO_LN = 1, PRO_16 = 2, PRO_ATTN = 3 };
-enum { EPI_ACT16 = 0, EPI_RESID32 = 1, EPI_BIAS32 = 2 };
-
-struct TfArgs {
-  const void* A;            // PRO_F32 / PRO_LN: float [M, lda]; PRO_16: 16-bit [M, lda]
-  int lda;
-  const float* ln_g;        // PRO_LN
-  const float* ln_b;
-  float eps;
-  float* xout;              // PRO_LN, optional: LN(A) as fp32 [M, K] (residual operand of a later launch)
-  const uint16_t* q;        // PRO_ATTN: q / k in FRAGMENT-MAJOR layout (tf_frag_off), v row-major [B*Tk, ldv] (head h at columns h*DH..)
-  const uint16_t* k;
-  const uint16_t* v;
-  int ldv;
-  uint16_t* frag[2];        // EPI_ACT16, optional: output columns [i*frag_D, (i+1)*frag_D) go to frag[i] in fragment-major layout
-  int frag_D, frag_T, frag_H, frag_DH;   // instead of `out` (the q / k operands of the fused attention prologue)
-  const uint8_t* kmask;     // [B, Tk], 1 = attend; may be null
-  int T, Tk, H, B, cpb;     // cpb: clips per row block
-  float scale;
-  const uint16_t* W;        // [N, K] 16-bit, row stride ldw
-  int ldw;
-  const float* bias;
-  const float* resid;       // EPI_RESID32: fp32 [M, ldres]
-  int ldres;
-  void* out;
-  int ldo;
-  int M, N, K;
-  int rpb;                  // token rows per row block (<= 32)
-  int n_tiles, n_rb;
-  int act;
-};
-
-__device__ __forceinline__ int swz16(int chunk, int row) { return chunk ^ (row & 15); }
-
-// Fragment-major layout of a q / k matrix: the 16 B an MFMA lane needs (token r of a 16-token tile, head-dim chunk 4 kk + qq)
-// sit at lane (16 qq + r) x 16 B of a 1-KiB record per (clip, head, token tile, kk) -- one fully coalesced wave load per
-// fragment, where row-major [token][feature] rows give 16 rows x 64 B per instruction (measured: the fragment-shaped loads
-// of 2 (clip, head) pairs cost 3.7 us of a 9.9 us launch).  Element offset of (clip, head, token t, head-dim d):
-__host__ __device__ __forceinline__ size_t tf_frag_off(int clip, int head, int t, int d, int H, int DH) {
-  const int KK = DH >> 5;
-  return ((((size_t)(clip * H + head) * 2 + (t >> 4)) * KK + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (t & 15)) * 8 + (d & 7);
-}
-__host__ __device__ __forceinline__ size_t tf_frag_elems(int clips, int H, int DH) { return (size_t)clips * H * 2 * (DH >> 5) * 512; }
-
-// (n tile, row block) of a block id: blocks that share a W tile agree mod 8 -> same XCD (round-robin dispatch).
-__device__ __forceinline__ void tf_block_map(int bid, int n_tiles, int n_rb, int& nt, int& rb) {
-  const int n8 = n_tiles & ~7;
-  if (bid < n8 * n_rb) {
-    const int g = bid >> 3;
-    rb = g % n_rb;
-    nt = (g / n_rb) * 8 + (bid & 7);
-  } else {
-    const int rem = bid - n8 * n_rb, tail = n_tiles - n8;
-    nt = n8 + rem % tail;
-    rb = rem / tail;
-  }
-}
-
-// W tile [BN rows x K] -> LDS image by LDS-DMA; image chunk p = (row, phys) holds logical chunk phys ^ (row & 15).
-__device__ __forceinline__ void tf_stage_w(const TfArgs& a, char* w_img, int n0, int BN, int wave, int lane, int nw) {
-  const int cpr = a.K >> 3;                    // 16-B chunks per row
-  const int total = (BN * cpr) >> 6;           // wave instructions (64 chunks each)
-  for (int ii = wave; ii < total; ii += nw) {
-    const int p = ii * 64 + lane;
-    const int row = p / cpr, phys = p - row * cpr;
-    const int nrow = min(n0 + row, a.N - 1);   // rows past N (odd head widths) re-read the last row; never stored
-    const uint16_t* src = a.W + (size_t)nrow * a.ldw + (swz16(phys, row) << 3);
-    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(w_img + ii * 1024), 16, 0, 0);
-  }
-}
-
-// ---- A operand producers --------------------------------------------------------------------------------------------
-// thread t: row t / TPR, TPR = 2 NW threads per row, float4 at columns 4*(t8 + TPR i).
-// The GEMM consumes z = (y - mean) * rstd: gamma is folded into the packed weight columns and beta W^T into the packed bias
-// (LN(y) W^T + b = z (W . gamma)^T + (b + W beta)), so the 32 row groups do not each re-read gamma and beta.  The fp32 side
-// output x = z * gamma + beta (the residual operand of a later launch) needs them only for this block's BN columns.
-template <typename T, int KD, int BN, int NW>
-__device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, int nt, int tid) {
-  constexpr int TPR = 2 * NW;                    // threads per row (32 rows x TPR = 64 NW threads)
-  constexpr int NI = KD / (4 * TPR);
-  const int row = tid / TPR, t8 = tid % TPR;
-  const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
-  const float* src = (const float*)a.A + (size_t)grow * a.lda;
-  float4 x[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) x[i] = *(const float4*)(src + 4 * (t8 + TPR * i));
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-#pragma unroll
-  for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
-  const float mean = s * (1.0f / KD);
-  float v = 0.f;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-    v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
-  }
-#pragma unroll
-  for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o, 64);
-  const float rstd = rsqrtf(v * (1.0f / KD) + a.eps);
-  const bool emit = a.xout != nullptr && row < a.rpb && rb * a.rpb + row < a.M;
-  float* xo = a.xout + (size_t)grow * KD;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c4 = t8 + TPR * i;
-    float4 z;
-    z.x = x[i].x * rstd; z.y = x[i].y * rstd; z.z = x[i].z * rstd; z.w = x[i].w * rstd;
-    if (emit && (4 * c4) / BN == nt) {            // this block's BN columns of the fp32 side output
-      const float4 g = *(const float4*)(a.ln_g + 4 * c4), b = *(const float4*)(a.ln_b + 4 * c4);
-      *(float4*)(xo + 4 * c4) = make_float4(z.x * g.x + b.x, z.y * g.y + b.y, z.z * g.z + b.z, z.w * g.w + b.w);
-    }
-    *(uint2*)(a_img + row * (KD * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
-        make_uint2(pack2<T>(z.x, z.y), pack2<T>(z.z, z.w));
-  }
-}
-
-template <typename T, int NW>
-__device__ __forceinline__ void tf_pro_f32(const TfArgs& a, char* a_img, int rb, int tid) {
-  constexpr int TPR = 2 * NW;
-  const int row = tid / TPR, t8 = tid % TPR;
-  const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
-  const float* src = (const float*)a.A + (size_t)grow * a.lda;
-  const int ni = a.K / (4 * TPR);
-  for (int i0 = 0; i0 < ni; i0 += 8) {
-    float4 x[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i0 + i < ni) x[i] = *(const float4*)(src + 4 * (t8 + TPR * (i0 + i)));
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i0 + i < ni) {
-        const int c4 = t8 + TPR * (i0 + i);
-        *(uint2*)(a_img + row * (a.K * 2) + (swz16(c4 >> 1, row) << 4) + ((c4 & 1) << 3)) =
-            make_uint2(pack2<T>(x[i].x, x[i].y), pack2<T>(x[i].z, x[i].w));
-      }
-  }
-}
-
-// 16-bit A rows by LDS-DMA (same image as W)
-__device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, int wave, int lane, int nw) {
-  const int cpr = a.K >> 3;
-  const int total = (TF_BM * cpr) >> 6;
-  for (int ii = wave; ii < total; ii += nw) {
-    const int p = ii * 64 + lane;
-    const int row = p / cpr, phys = p - row * cpr;
-    const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
-    const uint16_t* src = (const uint16_t*)a.A + (size_t)grow * a.lda + (swz16(phys, row) << 3);
-    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(a_img + ii * 1024), 16, 0, 0);
-  }
-}
-
-// V rows of the block's clips -> LDS image [vrows][D] by LDS-DMA: vrows = (cpb-1)*Tk + 16*NKT, NKT = key tiles (Tk <= 16: keys
-// 16..31 of the 32-key P V step are fed as zeros, no LDS rows); rows past the data repeat the last key (finite values under
-// a zero probability).
-__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int vrows, int wave, int lane, int nw) {
-  const int cpr = a.K >> 3;
-  const int total = (vrows * cpr + 63) >> 6;
-  const int c0 = rb * a.cpb;
-  for (int ii = wave; ii < total; ii += nw) {
-    const int p = min(ii * 64 + lane, vrows * cpr - 1);
-    const int row = p / cpr, phys = p - row * cpr;
-    const int ci = min(row / a.Tk, a.cpb - 1);
-    const int key = min(row - ci * a.Tk, a.Tk - 1);
-    const int clip = min(c0 + ci, a.B - 1);
-    const uint16_t* src = a.v + ((size_t)clip * a.Tk + key) * a.ldv + (swz16(phys, row) << 3);
-    __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(v_img + ii * 1024), 16, 0, 0);
-  }
-}
-
-// Masked attention of the block's (clip, head) pairs; one wave per pair, PB pairs in flight per wave.  S^T = K Q^T with the
-// K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
-// of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
-// operand of the out_proj GEMM.
-template <int DH, int QT, int NKT, int NW>
-struct TfAttnFrags {
-  static constexpr int KK = DH / 32, PB = (16 / NW) / QT;     // (clip, head) pairs in flight per wave
-  uint4 kf[PB][NKT][KK], qf[PB][QT][KK];
-  uint32_t livebits[2];
-};
-
-// K / Q fragments of this wave's first PB (clip, head) pairs (fragment-major buffers: one coalesced 1-KiB load each) + the
-// liveness of this lane's keys: plain global loads, issued together with the LDS-DMA of the V and W images so that one round
-// trip covers all of them.  Token rows >= T (or Tk) of a tile were never written: they only reach masked scores / unused rows.
-template <int DH, int QT, int NKT, int NW>
-__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, int rb, int p0, int lane) {
-  constexpr int KK = DH / 32, PB = (16 / NW) / QT;
-  const int c0 = rb * a.cpb, npairs = a.cpb * a.H;
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int p = min(p0 + i, npairs - 1);
-    const int ci = p / a.H, h = p - ci * a.H;
-    const int clip = min(c0 + ci, a.B - 1);
-    const size_t rec = (size_t)(clip * a.H + h) * 2 * KK;       // 1-KiB records of this (clip, head): [token tile][kk]
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(a.k + (rec + nt * KK + kk) * 512 + lane * 8);
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(a.q + (rec + qt * KK + kk) * 512 + lane * 8);
-  }
-}
-
-__device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebits)[2], int rb, int lane) {
-  const int q = lane >> 4, c0 = rb * a.cpb;
-  livebits[0] = livebits[1] = 0u;
-#pragma unroll
-  for (int ci = 0; ci < 2; ++ci) {
-    const int clip = min(c0 + min(ci, a.cpb - 1), a.B - 1);
-    uint32_t lo = 0x01010101u, hi = 0x01010101u;                  // mask bytes of keys 4q..4q+3 and 16+4q..
-    if (a.kmask != nullptr) {
-      const uint8_t* mk = a.kmask + (size_t)clip * a.Tk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k0 = 4 * q + j, k1 = 16 + 4 * q + j;
-        const uint32_t m0 = mk[min(k0, a.Tk - 1)], m1 = mk[min(k1, a.Tk - 1)];
-        lo = (lo & ~(0xFFu << (8 * j))) | ((m0 ? 1u : 0u) << (8 * j));
-        hi = (hi & ~(0xFFu << (8 * j))) | ((m1 ? 1u : 0u) << (8 * j));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (4 * q + j < a.Tk && ((lo >> (8 * j)) & 1u)) livebits[ci] |= 1u << j;
-      if (16 + 4 * q + j < a.Tk && ((hi >> (8 * j)) & 1u)) livebits[ci] |= 1u << (4 + j);
-    }
-  }
-}
-
-// Masked attention of the block's (clip, head) pairs; one wave per pair, PB pairs in flight per wave.  S^T = K Q^T with the
-// K and Q fragments loaded straight from global (16 rows x 64 B per instruction), P stays in registers as the B operand
-// of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
-// operand of the out_proj GEMM.
-template <typename T, int DH, int QT, int NKT, int NW>
-__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, char* a_img, const char* v_img, int rb, int wave,
-                                            int lane) {
-  constexpr int KK = DH / 32, DT = DH / 16, PB = (16 / NW) / QT;
-  const int r = lane & 15, q = lane >> 4;
-  const int npairs = a.cpb * a.H;
-  const int rowb = a.K * 2;
-  const float c2 = a.scale * 1.4426950408889634f;
-  const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
-  for (int p0 = wave * PB; p0 < npairs; p0 += NW * PB) {
-    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT, NW>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const bool valid = p0 + i < npairs;           // no early exit: the PB chains are independent and get interleaved
-      const int p = min(p0 + i, npairs - 1);
-      const int ci = p / a.H, h = p - ci * a.H;
-      const uint32_t lb = ci ? f.livebits[1] : f.livebits[0];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        f32x4 s[2];
-        s[1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // NKT == 1: keys 16..31 do not exist
-#pragma unroll
-        for (int nt = 0; nt < NKT; ++nt) {
-          s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < KK; ++kk) s[nt] = T::mfma16(f.kf[i][nt][kk], f.qf[i][qt][kk], s[nt]);
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (!((lb >> (4 * nt + j)) & 1u)) s[nt][j] = -INFINITY;
-            m = fmaxf(m, s[nt][j]);
-          }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float mc = m * c2;                  // a fully masked row gives exp2(NaN): NaN output, as torch
-        uint4 pf;
-        pf.x = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][1], c2, -mc)));
-        pf.y = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[0][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][3], c2, -mc)));
-        pf.z = pf.w = 0u;
-        if constexpr (NKT == 2) {
-          pf.z = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][0], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][1], c2, -mc)));
-          pf.w = pack2<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s[1][2], c2, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][3], c2, -mc)));
-        }
-        f32x4 osum = T::mfma16(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f});
-        f32x4 o[DT];
-        // transposed 4-key x 16-column blocks: this lane supplies key row 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
-        const int vrow0 = ci * a.Tk + 4 * q + (r >> 2);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int col = h * DH + 16 * dt + 4 * (r & 3);
-          const char* p0a = v_img + vrow0 * rowb + (swz16(col >> 3, vrow0) << 4) + (((col >> 2) & 1) << 3);
-          const char* p1a = v_img + (vrow0 + 16) * rowb + (swz16(col >> 3, vrow0 + 16) << 4) + (((col >> 2) & 1) << 3);
-          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0a);
-          uint2 x1 = make_uint2(0u, 0u);
-          if constexpr (NKT == 2) x1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a));
-          const uint2 x0 = __builtin_bit_cast(uint2, v0);
-          o[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pf, (f32x4){0.f, 0.f, 0.f, 0.f});
-        }
-        const float inv = 1.0f / osum[0];
-        const int arow = ci * a.T + 16 * qt + r;   // row of the A image
-        if (valid && 16 * qt + r < a.T) {
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int col = h * DH + 16 * dt + 4 * q;
-            *(uint2*)(a_img + arow * rowb + (swz16(col >> 3, arow) << 4) + (((col >> 2) & 1) << 3)) =
-                make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
-          }
-        }
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ uint32_t tf_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(const VMC_LDS char*)p; }
-
-// ---- epilogue: one lane's 4 consecutive columns of one row -------------------------------------------------------------
-// pre_added: bias (and residual) are already inside v (tf_gemm_body seeds the accumulators with them)
-// frag_dst: (EPI_ACT16) where this lane's 4 columns go in a fragment-major side buffer, or nullptr for the row-major output
-template <typename T, int EPI>
-__device__ __forceinline__ void tf_epilogue(const TfArgs& a, int grow, int col, f32x4 v, bool pre_added = false,
-                                            uint16_t* frag_dst = nullptr) {
-  if (col >= a.N) return;
-  if (col + 3 < a.N) {
-    if (!pre_added) {
-      const float4 b = *(const float4*)(a.bias + col);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      if (EPI == EPI_RESID32) {
-        const float4 rr = *(const float4*)(a.resid + (size_t)grow * a.ldres + col);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-      }
-    }
-    if (EPI == EPI_ACT16) {
-      const uint2 o = make_uint2(pack2<T>(apply_act_rt(v[0], a.act), apply_act_rt(v[1], a.act)),
-                                 pack2<T>(apply_act_rt(v[2], a.act), apply_act_rt(v[3], a.act)));
-      if (frag_dst != nullptr) {                    // q / k columns: fragment-major side buffer
-        *(uint2*)frag_dst = o;
-      } else {
-        *(uint2*)((uint16_t*)a.out + (size_t)grow * a.ldo + col) = o;
-      }
-    } else if ((a.ldo & 3) == 0) {
-      *(float4*)((float*)a.out + (size_t)grow * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ((float*)a.out)[(size_t)grow * a.ldo + col + j] = v[j];
-    }
-  } else {                                       // ragged last columns (class count not a multiple of 4)
-    for (int j = 0; j < 4 && col + j < a.N; ++j) {
-      float x = v[j] + a.bias[col + j];
-      if (EPI == EPI_RESID32) x += a.resid[(size_t)grow * a.ldres + col + j];
-      if (EPI == EPI_ACT16) ((uint16_t*)a.out)[(size_t)grow * a.ldo + col + j] = T::from_f32(apply_act_rt(x, a.act));
-      else ((float*)a.out)[(size_t)grow * a.ldo + col + j] = x;
-    }
-  }
-}
-
-// ---- single-shot K kernel ----------------------------------------------------------------------------------------------
-// LDS: [A image 32 x K][W image BN x K][V image (PRO_ATTN)]; the K-slice exchange of the accumulators re-uses the A image
-// Every global access of the prologue (A rows / LayerNorm parameters / K, Q fragments / mask bytes / the LDS-DMA of the W
-// and V images) is issued before the first wait, so a workgroup pays ONE memory round trip before its MFMAs.
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT, int NW>
-__device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_smem) {
-  constexpr int NTN = BN / 16;
-  constexpr int ROWB = KD * 2;
-  constexpr int KSP = NW / 2;                    // K slices (waves = 2 row tiles x KSP K slices)
-  constexpr int KSTEPS = KD / 32 / KSP;          // 32-wide k-steps per slice
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int nt, rb;
-  tf_block_map(bid, a.n_tiles, a.n_rb, nt, rb);
-  char* a_img = tf_smem;
-  char* w_img = a_img + TF_BM * ROWB;
-  char* v_img = w_img + BN * ROWB;
-  char* red = a_img;                             // K-slice exchange re-uses the A image once every wave is past its MFMAs
-  const int n0 = nt * BN;
-
-  if constexpr (PRO == PRO_ATTN) {
-    TfAttnFrags<DH, QT, NKT, NW> fr;
-    tf_attn_load<DH, QT, NKT, NW>(a, fr, rb, wave * ((16 / NW) / QT), lane);
-    tf_attn_live(a, fr.livebits, rb, lane);
-    tf_stage_v(a, v_img, rb, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane, NW);
-    tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                             // V (and W) images complete
-    tf_pro_attn<T, DH, QT, NKT, NW>(a, fr, a_img, v_img, rb, wave, lane);
-  } else {
-    tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
-    if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane, NW);
-    if constexpr (PRO == PRO_LN) tf_pro_ln<T, KD, BN, NW>(a, a_img, rb, nt, tid);
-    if constexpr (PRO == PRO_F32) tf_pro_f32<T, NW>(a, a_img, rb, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-
-  const int r = lane & 15, q = lane >> 4;
-  const int rt = wave & 1, ks = wave >> 1;
-  f32x4 acc[NTN];
-#pragma unroll
-  for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int arow = 16 * rt + r;
-  const int grow_e = rb * a.rpb + arow;
-  const bool store_e = ks == 0 && arow < a.rpb && grow_e < a.M;
-  if (store_e && a.N % 4 == 0) {
-    // the epilogue's bias (+ residual) operands ride under the MFMA loop: start the K-slice-0 accumulators from them
-#pragma unroll
-    for (int n = 0; n < NTN; ++n) {
-      const int col = n0 + 16 * n + 4 * q;
-      if (col < a.N) {
-        const float4 b = *(const float4*)(a.bias + col);
-        acc[n] = (f32x4){b.x, b.y, b.z, b.w};
-        if constexpr (EPI == EPI_RESID32) {
-          const float4 rr = *(const float4*)(a.resid + (size_t)grow_e * a.ldres + col);
-          acc[n] += (f32x4){rr.x, rr.y, rr.z, rr.w};
-        }
-      }
-    }
-  }
-  const bool pre_added = a.N % 4 == 0;
-  const char* ap = a_img + arow * ROWB;
-  constexpr int KB = KSTEPS % 4 == 0 ? 4 : (KSTEPS % 3 == 0 ? 3 : (KSTEPS % 2 == 0 ? 2 : 1));   // k-steps whose reads are batched
-#pragma unroll
-  for (int k0 = 0; k0 < KSTEPS; k0 += KB) {
-    uint4 af[KB], wf[KB][NTN];
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      const int chunk = (ks * KSTEPS + k0 + kk) * 4 + q;
-      af[kk] = *(const uint4*)(ap + (swz16(chunk, arow) << 4));
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) {
-        const int wrow = 16 * n + r;
-        wf[kk][n] = *(const uint4*)(w_img + wrow * ROWB + (swz16(chunk, wrow) << 4));
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) acc[n] = T::mfma16(wf[kk][n], af[kk], acc[n]);
-  }
-  __syncthreads();
-  if (ks > 0) {
-#pragma unroll
-    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((((ks - 1) * 2 + rt) * NTN + n) * 64 + lane) * 16) = acc[n];
-  }
-  __syncthreads();
-  if (ks == 0) {
-    const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
-    if (lrow < a.rpb && grow < a.M) {
-      int fclip = 0, ft = 0;
-      if (EPI == EPI_ACT16 && a.frag_D > 0) {          // token coordinates of this lane's row: once, not per column tile
-        fclip = grow / a.frag_T;
-        ft = grow - fclip * a.frag_T;
-      }
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) {
-        f32x4 o = acc[n];
-#pragma unroll
-        for (int s2 = 0; s2 < KSP - 1; ++s2) o += *(const f32x4*)(red + (((s2 * 2 + rt) * NTN + n) * 64 + lane) * 16);
-        uint16_t* fdst = nullptr;
-        if (EPI == EPI_ACT16 && a.frag_D > 0) {
-          const int c0 = __builtin_amdgcn_readfirstlane(n0 + 16 * n);      // wave-uniform: scalar divisions
-          const int fi = c0 / a.frag_D;
-          if (fi < 2 && a.frag[fi] != nullptr) {      // a 16-column MFMA tile never straddles a head (head_dim % 16 == 0)
-            const int c = c0 - fi * a.frag_D, head = c / a.frag_DH, d = c - head * a.frag_DH + 4 * q;
-            fdst = a.frag[fi] + tf_frag_off(fclip, head, ft, d, a.frag_H, a.frag_DH);
-          }
-        }
-        tf_epilogue<T, EPI>(a, grow, n0 + 16 * n + 4 * q, o, pre_added, fdst);
-      }
-    }
-  }
-}
-
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT, int NW>
-__global__ void __launch_bounds__(64 * NW) tf_gemm_kernel(const TfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
-  tf_gemm_body<T, BN, PRO, EPI, KD, DH, QT, NKT, NW>(a, blockIdx.x, tf_smem);
-}
-
-// Two independent problems in one launch: a layer's qkv projection (raw tokens or LayerNorm prologue) + the K|V projection of
-// the raw motion tokens for that layer's cross attention: neither depends on the other, so the K|V GEMM costs no launch of its own.
-template <typename T, int BN, int PRO, int EPI, int KD, int NW>
-__global__ void __launch_bounds__(64 * NW) tf_gemm_pair_kernel(const TfArgs a, const TfArgs b, int blocks_a) {
-  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
-  if ((int)blockIdx.x < blocks_a) tf_gemm_body<T, BN, PRO, EPI, KD, 64, 1, 1, NW>(a, blockIdx.x, tf_smem);
-  else tf_gemm_body<T, BN, PRO_F32, EPI, KD, 64, 1, 1, NW>(b, blockIdx.x - blocks_a, tf_smem);      // b: always raw fp32 rows
-}
-
-// ---- chunked-K kernel (FFN second linear): A 16-bit and W both by LDS-DMA through an NST-deep ring -----------------------
-template <int N>
-__device__ __forceinline__ void tf_wait_vm() {
-  if (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, int BN, int KC, int NST>
-__global__ void __launch_bounds__(TF_NTH) tf_gemm_ring_kernel(const TfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char tf_smem[];
-  constexpr int NTN = BN / 16;
-  constexpr int CPR = KC / 8;                          // 16-B chunks per image row
-  constexpr int A_INSTR = TF_BM * CPR / 64 / 4;        // LDS-DMA instructions per wave per chunk
-  constexpr int W_INSTR = (BN * CPR / 64 + 3) / 4;
-  constexpr int PER = A_INSTR + W_INSTR;
-  constexpr int STAGE = (TF_BM + BN) * KC * 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int nt, rb;
-  tf_block_map(blockIdx.x, a.n_tiles, a.n_rb, nt, rb);
-  const int n0 = nt * BN;
-  const int nchunks = a.K / KC;
-  char* red = tf_smem + NST * STAGE;
-
-  auto stage = [&](int c) {
-    char* base = tf_smem + (c % NST) * STAGE;
-    const size_t koff = (size_t)c * KC;
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-      const int ii = wave + 4 * i;
-      const int p = ii * 64 + lane, row = p / CPR, phys = p - row * CPR;
-      const int grow = min(rb * a.rpb + min(row, a.rpb - 1), a.M - 1);
-      const uint16_t* src = (const uint16_t*)a.A + (size_t)grow * a.lda + koff + (swz16(phys, row) << 3);
-      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(base + ii * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < W_INSTR; ++i) {
-      const int ii = min(wave + 4 * i, BN * CPR / 64 - 1);     // surplus instructions of a wave re-stage the last piece
-      const int p = ii * 64 + lane, row = p / CPR, phys = p - row * CPR;
-      const uint16_t* src = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + koff + (swz16(phys, row) << 3);
-      __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)src, (VMC_LDS void*)(base + TF_BM * KC * 2 + ii * 1024), 16, 0, 0);
-    }
-  };
-
-  const int r = lane & 15, q = lane >> 4;
-  const int rt = wave & 1, ks = wave >> 1;
-  f32x4 acc[NTN];
-#pragma unroll
-  for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < NST - 1; ++c)
-    if (c < nchunks) stage(c);
-  const int arow = 16 * rt + r;
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + NST - 1 < nchunks) {
-      stage(c + NST - 1);
-      tf_wait_vm<(NST - 1) * PER>();             // everything but the NST-1 youngest chunks has landed: chunk c is in
-    } else {
-      tf_wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    const char* a_img = tf_smem + (c % NST) * STAGE;
-    const char* w_img = a_img + TF_BM * KC * 2;
-    uint4 af[KC / 64], wf[NTN][KC / 64];
-#pragma unroll
-    for (int kk = 0; kk < KC / 64; ++kk) {
-      const int chunk = (ks * (KC / 64) + kk) * 4 + q;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(af[kk]) : "v"(tf_lds_addr(a_img + arow * (KC * 2) + (swz16(chunk, arow) << 4))) : "memory");
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) {
-        const int wrow = 16 * n + r;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(wf[n][kk]) : "v"(tf_lds_addr(w_img + wrow * (KC * 2) + (swz16(chunk, wrow) << 4))) : "memory");
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < KC / 64; ++kk)
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) acc[n] = T::mfma16(wf[n][kk], af[kk], acc[n]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                // ring slot c % NST may be restaged by the next iteration
-  }
-  if (ks == 1) {
-#pragma unroll
-    for (int n = 0; n < NTN; ++n) *(f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16) = acc[n];
-  }
-  __syncthreads();
-  if (ks == 0) {
-    const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
-    if (lrow < a.rpb && grow < a.M) {
-#pragma unroll
-      for (int n = 0; n < NTN; ++n) {
-        const f32x4 o = *(const f32x4*)(red + ((rt * NTN + n) * 64 + lane) * 16);
-        tf_epilogue<T, EPI_RESID32>(a, grow, n0 + 16 * n + 4 * q, acc[n] + o);
-      }
-    }
-  }
-}
-
-// ---- mean-pool + the two LayerNorms of the tail: pooled16[b] = LN_cls(mean_t LN_ffn(y[b, t])) ------------------------------
-template <typename T, int D>
-__global__ void __launch_bounds__(256) tf_pool_kernel(const float* __restrict__ y, const float* __restrict__ g1, const float* __restrict__ b1,
-                                                      const float* __restrict__ g2, const float* __restrict__ b2,
-                                                      uint16_t* __restrict__ out, int Tn, float eps) {
-  constexpr int NI = D / 256;                    // float4 per lane per row
-  __shared__ float part[4][D];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  float4 accp[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) accp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = wave; t < Tn; t += 4) {
-    const float* row = y + ((size_t)b * Tn + t) * D;
-    float4 x[NI];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      x[i] = *(const float4*)(row + 4 * (lane + 64 * i));
-      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-      v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
-    }
-    const float rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const float4 g = *(const float4*)(g1 + 4 * (lane + 64 * i)), bb = *(const float4*)(b1 + 4 * (lane + 64 * i));
-      accp[i].x += x[i].x * rstd * g.x + bb.x; accp[i].y += x[i].y * rstd * g.y + bb.y;
-      accp[i].z += x[i].z * rstd * g.z + bb.z; accp[i].w += x[i].w * rstd * g.w + bb.w;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) *(float4*)(&part[wave][4 * (lane + 64 * i)]) = accp[i];
-  __syncthreads();
-  if (wave == 0) {
-    float4 x[NI];
-    float s = 0.f;
-    const float invT = 1.0f / Tn;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      const float4 p0 = *(const float4*)(&part[0][c]), p1 = *(const float4*)(&part[1][c]), p2 = *(const float4*)(&part[2][c]),
-                   p3 = *(const float4*)(&part[3][c]);
-      x[i].x = ((p0.x + p1.x) + (p2.x + p3.x)) * invT; x[i].y = ((p0.y + p1.y) + (p2.y + p3.y)) * invT;
-      x[i].z = ((p0.z + p1.z) + (p2.z + p3.z)) * invT; x[i].w = ((p0.w + p1.w) + (p2.w + p3.w)) * invT;
-      s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-      v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
-    }
-    const float rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      const float4 g = *(const float4*)(g2 + c), bb = *(const float4*)(b2 + c);
-      *(uint2*)(out + (size_t)b * D + c) = make_uint2(pack2<T>(x[i].x * rstd * g.x + bb.x, x[i].y * rstd * g.y + bb.y),
-                                                      pack2<T>(x[i].z * rstd * g.z + bb.z, x[i].w * rstd * g.w + bb.w));
-    }
-  }
-}
-
-// ---- pack time: fold a LayerNorm's affine part into the linear that consumes it -------------------------------------------
-// w16[r, k] = W[r, k] * gamma[k] (16-bit), bias_out[r] = bias[r] + sum_k W[r, k] * beta[k] (fp32); one wave per row.
-template <typename T>
-__global__ void __launch_bounds__(256) tf_fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ bias,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         uint16_t* __restrict__ w16, float* __restrict__ bias_out, int rows, int cols) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* wr = W + (size_t)row * cols;
-  float acc = 0.f;
-  for (int c = 4 * lane; c < cols; c += 256) {
-    const float4 w = *(const float4*)(wr + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-    acc += (w.x * b.x + w.y * b.y) + (w.z * b.z + w.w * b.w);
-    *(uint2*)(w16 + (size_t)row * cols + c) = make_uint2(pack2<T>(w.x * g.x, w.y * g.y), pack2<T>(w.z * g.z, w.w * g.w));
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) bias_out[row] = bias[row] + acc;
-}
-
-// ---- host side ---------------------------------------------------------------------------------------------------------
-constexpr size_t TF_LDS_MAX = 160 * 1024;
-
-constexpr int TF_NW = 8;       // waves per workgroup of the single-shot kernels (2 row tiles x 4 K slices)
-
-template <int BN, int PRO, int KD, int NKT>
-constexpr size_t tf_lds_bytes(int cpb, int Tk) {
-  return (size_t)(TF_BM + BN) * KD * 2 +
-         (PRO == PRO_ATTN ? (size_t)((cpb - 1) * Tk + 16 * NKT) * KD * 2 + 1024 : 0);    // + one LDS-DMA piece of slack
-}
-
-template <typename K>
-int tf_set_lds(K kern, bool& done) {
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TF_LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-  }
-  return 0;
-}
-
-template <typename T, int BN, int PRO, int EPI, int KD, int DH, int QT, int NKT = 1>
-int tf_launch(TfArgs& a, hipStream_t s) {
-  const size_t lds = tf_lds_bytes<BN, PRO, KD, NKT>(a.cpb, a.Tk);
-  if (lds > TF_LDS_MAX || a.K != KD) return VMC_E_SHAPE;
-  if ((TF_NW / 2 - 1) * 2 * (BN / 16) * 1024 > TF_BM * KD * 2) return VMC_E_SHAPE;      // K-slice exchange must fit the A image
-  a.n_tiles = (a.N + BN - 1) / BN;
-  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
-  auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT, NKT, TF_NW>;
-  static bool attr_done = false;                // per instantiation
-  if (int rc = tf_set_lds(kern, attr_done)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(64 * TF_NW), lds, s, a);
-  VMC_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int BN, int PRO, int EPI, int KD>
-int tf_launch_pair(TfArgs& a, TfArgs& b, hipStream_t s) {
-  const size_t lds = tf_lds_bytes<BN, PRO, KD, 1>(1, 0);
-  if (lds > TF_LDS_MAX || a.K != KD || b.K != KD) return VMC_E_SHAPE;
-  a.n_tiles = (a.N + BN - 1) / BN; a.n_rb = (a.M + a.rpb - 1) / a.rpb;
-  b.n_tiles = (b.N + BN - 1) / BN; b.n_rb = (b.M + b.rpb - 1) / b.rpb;
-  auto kern = tf_gemm_pair_kernel<T, BN, PRO, EPI, KD, TF_NW>;
-  static bool attr_done = false;
-  if (int rc = tf_set_lds(kern, attr_done)) return rc;
-  const int na = a.n_tiles * a.n_rb;
-  hipLaunchKernelGGL(kern, dim3(na + b.n_tiles * b.n_rb), dim3(64 * TF_NW), lds, s, a, b, na);
-  VMC_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int BN, int KC, int NST>
-int tf_launch_ring(TfArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NST * (TF_BM + BN) * KC * 2 + 2 * (BN / 16) * 1024;
-  if (lds > TF_LDS_MAX || a.K % KC) return VMC_E_SHAPE;
-  a.n_tiles = (a.N + BN - 1) / BN;
-  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
-  auto kern = tf_gemm_ring_kernel<T, BN, KC, NST>;
-  static bool attr_done = false;
-  if (int rc = tf_set_lds(kern, attr_done)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles * a.n_rb), dim3(TF_NTH), lds, s, a);
-  VMC_CHECK_LAUNCH();
-  return 0;
-}
-
-// Output-column tile.  A workgroup's cost is one memory round trip plus (32 A rows + BN W rows) x K bytes at the ~70 GB/s one
-// CU pulls from L2, whatever BN is; what BN decides is how many workgroups there are.  Take the narrowest tile (most CUs
-// streaming W) whose grid still fits one resident round (2 workgroups per CU while the LDS footprint allows, else 1).
-inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn, int vrows = 48) {
-  const int n_rb = (M + rpb - 1) / rpb;
-  const int cands[4] = {16, 32, 48, 64};
-  int best = 16;
-  for (int i = 0; i < 4; ++i) {
-    const int bn = cands[i];
-    if (N % bn && !(N < bn)) continue;
-    if (attn && bn > 32) break;
-    const size_t lds = (size_t)(TF_BM + bn) * K * 2 + (attn ? (size_t)vrows * K * 2 + 1024 : 0);
-    if (lds > TF_LDS_MAX) break;
-    best = bn;
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    if ((long)((N + bn - 1) / bn) * n_rb <= 256L * per_cu) break;
-  }
-  return best;
-}
-
-#define TF_BN_SWITCH(bn, CALL)            \
-  switch (bn) {                           \
-    case 64: return CALL(64);             \
-    case 48: return CALL(48);             \
-    case 32: return CALL(32);             \
-    default: return CALL(16);             \
-  }
-
-template <typename T, int PRO, int EPI, int KD>
-int tf_dispatch_bn(TfArgs& a, int bn, hipStream_t s) {
-#define TF_CALL(BNV) tf_launch<T, BNV, PRO, EPI, KD, 64, 1>(a, s)
-  TF_BN_SWITCH(bn, TF_CALL)
-#undef TF_CALL
-}
-
-template <typename T, int KD, int BN, int DH>
-int tf_dispatch_attn3(TfArgs& a, hipStream_t s) {
-  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 16 ? 2 : 1;
-  if (qt == 1 && nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 1>(a, s);
-  if (qt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 2>(a, s);
-  if (nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 2, 1>(a, s);
-  return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 2, 2>(a, s);
-}
-
-template <typename T, int KD>
-int tf_dispatch_attn(TfArgs& a, int bn, int dh, hipStream_t s) {
-  if (bn == 32) return dh == 64 ? tf_dispatch_attn3<T, KD, 32, 64>(a, s) : tf_dispatch_attn3<T, KD, 32, 96>(a, s);
-  return dh == 64 ? tf_dispatch_attn3<T, KD, 16, 64>(a, s) : tf_dispatch_attn3<T, KD, 16, 96>(a, s);
-}
-
-struct TfDims {
-  int B, T, Tk, D, H, ff, L, C, has_cross;
-};
-
-inline int tf_check(const TfDims& d) {
-  if (d.B <= 0 || d.T <= 0 || d.T > 32 || d.L <= 0 || d.C <= 0) return VMC_E_SHAPE;
-  if (d.D != 512 && d.D != 768) return VMC_E_SHAPE;
-  if (d.H <= 0 || d.D % d.H) return VMC_E_SHAPE;
-  const int dh = d.D / d.H;
-  if (dh != 64 && dh != 96) return VMC_E_SHAPE;
-  if (d.ff % 512 || d.ff <= 0) return VMC_E_SHAPE;
-  if (d.has_cross && (d.Tk <= 0 || d.Tk > 32)) return VMC_E_SHAPE;
-  const int cpb = d.T <= 16 ? 2 : 1;
-  if ((cpb * d.H) % 4) return VMC_E_SHAPE;
-  return 0;
-}
-
-}  // namespace
+#include "tfam_kernels.h"
 
 // ---- pack layout ---------------------------------------------------------------------------------------------------------
 // 16-bit weight pack: per layer [self_in 3D x D | self_out D x D | cross_q D x D | cross_out D x D | ffn0 ff x D | ffn3 D x ff],
