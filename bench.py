@@ -366,7 +366,7 @@ def tfam_small_batch_train(dev, cdt, m, batches=(8, 64, 512), iters=30):
     device memory, advanced by vmc_train_tick inside the graph).  Single process; wall clock around synchronised loops."""
     from vimo_clip_amd import synth
     from vimo_clip_amd.graphs import GraphedTrainStep
-    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.losses import bce_with_logits_loss, loss_and_grad
     from vimo_clip_amd.optim import FusedAdam, GradArena
     m.train()
     opt = FusedAdam(GradArena(m.used_parameters()), lr=1e-4, weight_decay=0.1, decoupled=True)
@@ -387,19 +387,49 @@ def tfam_small_batch_train(dev, cdt, m, batches=(8, 64, 512), iters=30):
     m.use_device_seeds(opt)
 
     def dev_step(rgb, mot, mk, y):
-        opt.tick()
+        opt.tick()                                                     # the step of TFAM/train_and_eval.ModelTrainer._device_state_step
         out = m(rgb, mot, mask_rgb=mk, mask_flow=mk)
-        loss = bce_with_logits_loss(out, y)
-        loss.backward()
+        loss, dlogits = loss_and_grad(bce_with_logits_loss, out, y)
+        out.backward(dlogits)
         opt.step()
-        return loss.detach(), out.detach()
+        return loss, out.detach()
 
     g = GraphedTrainStep(dev_step, opt)
+    p_used = tfam_hbm_bytes(8)[1]
+    evict = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     for B in batches:
         rgb, mot, mk, y = data[B]
         t = _time_cuda(lambda: g(rgb, mot, mk, y), iters)
         res[f"B{B}_captured_ms"] = round(1e3 * t, 4)
         res[f"B{B}_captured_clips_per_s"] = round(B / t, 1)
+        if B > 64:
+            continue
+        # BYTES_train(B) = P_used * (2 e_w + 4 + 28) + activations: the 16-bit weights read by the forward and by the
+        # backward, the fp32 gradient written, AdamW's 16 B read + 12 B written per parameter; tokens in / logits out as BYTES_fwd.
+        # HIP events around ONE replay on its stream; "evicted" = 512 MiB streamed through another buffer before each replay.
+        nbytes = p_used * (2 * 2 + 4 + 28) + B * 32 * 768 * 4 + B * 32 + B * 140 * 4
+        gr = g._graphs[next(iter(k for k in g._graphs if k[0][0][0] == B))]
+        ts = []
+        for cold in (False, True):
+            evs = []
+            for _ in range(12):
+                if cold:
+                    evict.add_(1)
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                gr.replay()
+                s1.record()
+                evs.append((s0, s1))
+                opt.step_count += 1
+            torch.cuda.synchronize()
+            el = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)
+            ts.append(el[len(el) // 2])
+        res[f"B{B}_roofline"] = {"bound": "hbm", "bytes_train": nbytes, "peak": 8000.0, "unit": "GB/s",
+                                 "us_mall_resident": round(ts[0] * 1e6, 1), "us_evicted": round(ts[1] * 1e6, 1),
+                                 "achieved_mall_resident": round(nbytes / ts[0] / 1e9, 1), "achieved_evicted": round(nbytes / ts[1] / 1e9, 1),
+                                 "hbm_frac_mall_resident": round(nbytes / ts[0] / 8e12, 4), "hbm_frac_evicted": round(nbytes / ts[1] / 8e12, 4)}
+    res["launches_per_step_B8"] = "27 forward + 38 backward (fused chains, tfam_train.py) + tick, loss, AdamW, 16-bit copy refresh"
+    del evict
     m.use_device_seeds(None)
     return res
 

@@ -471,6 +471,10 @@ int vmc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
 int vmc_train_tick(void* state, float* hyper, float beta1, float beta2, int n_seeds, void* stream);
 int vmc_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
                       float eps, float weight_decay, int decoupled_wd, void* stream);
+/* The same update launched with at most max_workgroups workgroups of 256 threads: the geometry for an update that runs on a side
+ * stream BESIDE other kernels (FusedAdam.enable_backward_overlap: 2 per CU leaves the wave slots the backward's workgroups need). */
+int vmc_adam_step_dev_bg(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
+                         float eps, float weight_decay, int decoupled_wd, int max_workgroups, void* stream);
 /* sum of squares of a flat f32 buffer, accumulated (+=) into out[0] (global grad norm). */
 int vmc_sumsq(const float* x, size_t n, float* out, void* stream);
 

@@ -181,3 +181,45 @@ def test_unsupported_shapes_take_the_per_op_path(monkeypatch):
     m = _model(c)
     loss, _, grads = _step(m, c, True)
     assert calls in ([], [False]) and np.isfinite(loss) and grads       # declined by AMO_CLIP._fused_inputs or by forward_train
+
+
+@pytest.mark.parametrize("device_state", [False, True], ids=["host-scalars", "device-state"])
+def test_backward_overlapped_adamw_equals_the_plain_step(device_state):
+    """FusedAdam.enable_backward_overlap: AdamW (+ the 16-bit copy refresh) of a layer whose gradients are complete runs on a side
+    stream beside the backward of the layers below it.  Five steps with dropout on must leave exactly the parameters, moments and
+    16-bit copies of five plain steps (same kernels over sub-ranges of the same flat buffers: bit for bit)."""
+    from vimo_clip_amd import autograd_ops as ag
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    c = dict(CASES_ALL[0], L=3)
+    rgb, mot, mr, mf = (t.cuda() for t in mg.tfam_inputs(c))
+    y = synth.multi_hot_labels(c["seed"], "labels", c["B"], c["C"]).cuda()
+    runs = []
+    for overlap in (False, True):
+        m = _model(c, dropout=0.1, mlp_dropout=0.1)
+        opt = FusedAdam(GradArena(m.used_parameters()), lr=1e-3, weight_decay=0.1, decoupled=True)
+        if device_state:
+            opt.enable_device_state(base_seed=11)
+            m.use_device_seeds(opt)
+        else:
+            m.set_dropout_seed(11)
+        if overlap:
+            opt.enable_backward_overlap(m.parameter_groups_by_layer())
+            m.grad_group_callback = opt.group_ready
+            assert len(opt._ov["ranges"]) == c["L"] + 1 and not opt._ov["rest"]
+        losses = []
+        for _ in range(5):
+            if device_state:
+                opt.tick()
+            loss = bce_with_logits_loss(m(rgb, mot, mask_rgb=mr, mask_flow=mf), y)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        w16 = ag.weights.get(m.layers[1].ffn[0].weight, torch.bfloat16).clone()
+        runs.append((losses, opt.arena.flat_param.clone(), opt.m.clone(), opt.v.clone(), w16, opt.step_count))
+    a, b = runs
+    assert a[0] == b[0] and a[5] == b[5] == 5
+    for i in range(1, 5):
+        assert torch.equal(a[i], b[i]), i
+    assert a[0][0] != a[0][-1]

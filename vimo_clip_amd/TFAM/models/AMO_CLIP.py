@@ -225,6 +225,13 @@ class AMO_CLIP(nn.Module):
         pe = torch.zeros(1, seq_len, self.d_model, device=self.device)
         return ops.add_sinusoidal_pe_(pe)[0]
 
+    def parameter_groups_by_layer(self):
+        """[layer 0, ..., layer L-1, classifier]: the used parameters whose gradients the fused training chains complete together
+        (tfam_train.TfamTrainFn.backward reports group i through ``grad_group_callback(i)``; optim.FusedAdam.enable_backward_overlap)."""
+        used = {id(p) for p in self.used_parameters()}
+        groups = [[p for p in layer.parameters() if id(p) in used] for layer in self.layers]
+        return groups + [[p for p in self.classifier.parameters() if id(p) in used]]
+
     def used_parameters(self):
         """Parameters that receive a gradient in the configured fusion mode (the DDP all-reduce set;
         SURVEY.md §7 'DDP with unused parameters')."""

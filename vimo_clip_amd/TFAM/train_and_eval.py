@@ -206,18 +206,25 @@ class ModelTrainer:
             self.optimizer.enable_device_state(base_seed=config.seed)
             model.use_device_seeds(self.optimizer)
             self._graphed_train = GraphedTrainStep(self._device_state_step, self.optimizer)
+        if world == 1 and os.environ.get("VMC_ADAM_OVERLAP", "0") == "1":
+            # AdamW of a finished layer on a side stream beside the backward of the layers below it.  Bit-identical, but measured
+            # SLOWER on MI355X (captured B = 8 step 0.88 -> 0.95-1.01 ms: the fork / join edges of a multi-stream hipGraph cost more
+            # than the overlap returns; profiles/README.md), so it is opt-in
+            self.optimizer.enable_backward_overlap(model.parameter_groups_by_layer())
+            model.grad_group_callback = self.optimizer.group_ready
 
     def _forward(self, batch):
         return _model_forward(self.model, batch, self.config), batch["labels"].to(self.config.device)
 
     def _device_state_step(self, rgb, mot, mr, mf, labels):
         """tick + forward + loss + backward + AdamW with every step-dependent scalar read from device memory."""
+        from ..losses import loss_and_grad
         self.optimizer.tick()
         output = self.model(rgb, mot, mask_rgb=mr, mask_flow=mf)
-        loss = self.criterion(output, labels)
-        loss.backward()
+        loss, dlogits = loss_and_grad(self.criterion, output, labels)      # criterion(output, labels); loss.backward() (:81-83)
+        output.backward(dlogits)
         self.optimizer.step()
-        return loss.detach(), output.detach()
+        return loss, output.detach()
 
     def train_epoch(self, epoch):
         self.model.train()

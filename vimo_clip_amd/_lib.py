@@ -90,6 +90,7 @@ SIGNATURES = {
     "vmc_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, I, F, P]),
     "vmc_train_tick": (I, [P, P, F, F, I, P]),
     "vmc_adam_step_dev": (I, [P, P, P, P, Z, P, F, F, F, F, I, P]),
+    "vmc_adam_step_dev_bg": (I, [P, P, P, P, Z, P, F, F, F, F, I, I, P]),
     "vmc_sumsq": (I, [P, Z, P, P]),
 }
 

@@ -143,11 +143,11 @@ __device__ __forceinline__ void tn_tile_body(const uint16_t* __restrict__ dY, co
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b)
-            acc[a][b] = T::mfma16(make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y),
-                                  make_uint4(bf[b][0].x, bf[b][0].y, bf[b][1].x, bf[b][1].y), acc[a][b]);
+            acc[a][b] = T::mfma16(make_uint4(bf[b][0].x, bf[b][0].y, bf[b][1].x, bf[b][1].y),
+                                  make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y), acc[a][b]);      // (X, dY): 4 consecutive k per lane
         if (do_bias) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) bacc[a] = T::mfma16(make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y), ones, bacc[a]);
+          for (int a = 0; a < 4; ++a) bacc[a] = T::mfma16(ones, make_uint4(af[a][0].x, af[a][0].y, af[a][1].x, af[a][1].y), bacc[a]);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -156,29 +156,26 @@ __device__ __forceinline__ void tn_tile_body(const uint16_t* __restrict__ dY, co
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();      // balance the stagger
   }
-  // lane holds C[n = n0 + 64 wn + 16 a + 4 g + j][k = k0 + 64 wk + 16 b + r]
+  // operands passed as (X, dY): the lane holds C[n = n0 + 64 wn + 16 a + r][k = k0 + 64 wk + 16 b + 4 g + j], four consecutive k of
+  // one row -> one 16-byte store per accumulator (K % 8 == 0: a started group of four never crosses the edge); with (dY, X) the
+  // same tile left as 64 four-byte stores per lane and the store issue, not the 128 MB of a TFAM step's gradients, set the time
   float* out = C + (size_t)slab * N * K;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) {
+    const int n = n0 + 64 * wn + 16 * a + r;
+    if (n >= N) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 64 * wn + 16 * a + 4 * g + j;
-      if (n >= N) continue;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int k = k0 + 64 * wk + 16 * b + r;
-        if (k < K) out[(size_t)n * K + k] = acc[a][b][j];
-      }
+    for (int b = 0; b < 4; ++b) {
+      const int k = k0 + 64 * wk + 16 * b + 4 * g;
+      if (k < K) *(float4*)(out + (size_t)n * K + k) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
     }
-  if (do_bias && r == 0) {        // column 0 of the ones product: rows 4g + j of each 16-row block
+  }
+  if (do_bias && g == 0) {        // every row of the ones product carries the column sums: row 0 (g = 0, j = 0), column r
     float* bo = dbias + (size_t)slab * N;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + 64 * wn + 16 * a + 4 * g + j;
-        if (n < N) bo[n] = bacc[a][j];
-      }
+    for (int a = 0; a < 4; ++a) {
+      const int n = n0 + 64 * wn + 16 * a + r;
+      if (n < N) bo[n] = bacc[a][0];
+    }
   }
 }
-

@@ -113,6 +113,14 @@ __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, 
   float4 x[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) x[i] = *(const float4*)(src + 4 * (t8 + TPR * i));
+  float4 gam[TR ? NI : 1], bet[TR ? NI : 1];      // training: issued with the row loads, so the prologue stays ONE memory round trip
+  if constexpr (TR) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      gam[i] = *(const float4*)(a.ln_g + 4 * (t8 + TPR * i));
+      bet[i] = *(const float4*)(a.ln_b + 4 * (t8 + TPR * i));
+    }
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
@@ -138,7 +146,7 @@ __device__ __forceinline__ void tf_pro_ln(const TfArgs& a, char* a_img, int rb, 
     z.x = x[i].x * rstd; z.y = x[i].y * rstd; z.z = x[i].z * rstd; z.w = x[i].w * rstd;
     if constexpr (TR) {
       // training: unfolded weights, so the GEMM consumes LN(y) itself; its 16-bit rows are also the weight gradient's X operand
-      const float4 g = *(const float4*)(a.ln_g + 4 * c4), b = *(const float4*)(a.ln_b + 4 * c4);
+      const float4 g = gam[i], b = bet[i];
       z = make_float4(z.x * g.x + b.x, z.y * g.y + b.y, z.z * g.z + b.z, z.w * g.w + b.w);
       const uint2 z16 = make_uint2(pack2<T>(z.x, z.y), pack2<T>(z.z, z.w));
       if (live && ((4 * c4) / BN) % a.n_tiles == nt) {
@@ -179,6 +187,9 @@ __device__ __forceinline__ void tf_pro_lnbwd(const TfArgs& a, char* a_img, int r
 #pragma unroll
   for (int i = 0; i < NI; ++i)
     keep[i] = a.keep_in != nullptr ? *(const uint32_t*)(a.keep_in + (size_t)grow * KD + 4 * (t8 + TPR * i)) : 0x01010101u;
+  float4 gam[NI];                                // every global load of the prologue is issued before the first reduction
+#pragma unroll
+  for (int i = 0; i < NI; ++i) gam[i] = *(const float4*)(a.ln_g + 4 * (t8 + TPR * i));
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
@@ -197,7 +208,7 @@ __device__ __forceinline__ void tf_pro_lnbwd(const TfArgs& a, char* a_img, int r
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const float4 gm = *(const float4*)(a.ln_g + 4 * (t8 + TPR * i));
+    const float4 gm = gam[i];
     z[i].x *= rstd; z[i].y *= rstd; z[i].z *= rstd; z[i].w *= rstd;
     g[i].x *= gm.x; g[i].y *= gm.y; g[i].z *= gm.z; g[i].w *= gm.w;
     s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);

@@ -157,7 +157,8 @@ inline TrWs tr_ws(void* base, const TrDims& d) {
 inline TrLayerWs tr_lw(const TrWs& w, const TrDims& d, int layer) { return tr_layer_ws(w.layers + (size_t)layer * w.layer_bytes, d); }
 
 // ---- launch helpers (training instantiations; column tiles 16 / 32 / 64) ---------------------------------------------------
-inline int tr_pick_bn(int M, int N, int rpb, int K, bool attn, int vrows = 48) {
+// heavy: a LayerNorm (backward) prologue re-reads 32 fp32 rows (and more) per workgroup -- one workgroup per CU, wider tiles
+inline int tr_pick_bn(int M, int N, int rpb, int K, bool attn, bool heavy = false) {
   if (attn) return 16;
   const int n_rb = (M + rpb - 1) / rpb;
   const int cands[3] = {16, 32, 64};
@@ -168,10 +169,9 @@ inline int tr_pick_bn(int M, int N, int rpb, int K, bool attn, int vrows = 48) {
     const size_t lds = (size_t)(TF_BM + bn) * K * 2;
     if (lds > TF_LDS_MAX) break;
     best = bn;
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int per_cu = (lds <= 80 * 1024 && !heavy) ? 2 : 1;
     if ((long)(N / bn) * n_rb <= 256L * per_cu) break;
   }
-  (void)vrows;
   return best;
 }
 
@@ -185,7 +185,7 @@ int tr_dispatch_bn(TfArgs& a, int bn, hipStream_t s) {
 }
 template <typename T, int PRO, int EPI>
 int tr_gemm(TfArgs& a, hipStream_t s) {
-  const int bn = tr_pick_bn(a.M, a.N, a.rpb, a.K, false);
+  const int bn = tr_pick_bn(a.M, a.N, a.rpb, a.K, false, PRO == PRO_LN || PRO == PRO_LNBWD);
   if (bn != 16 && a.N % bn) return VMC_E_SHAPE;      // a ragged last tile (140 classes) only at the 16-column tile
   switch (a.K) {
     case 768: return tr_dispatch_bn<T, PRO, EPI, 768>(a, bn, s);
@@ -360,55 +360,108 @@ int tr_head_fwd(const vmc_tfam_layer_params* layers, const vmc_tfam_head_params&
   return 0;
 }
 
-// Head backward, 3 launches of fp32 FMAs (B <= 32 rows: 0.4 + 2.4 MFLOP of dgrad, the same of wgrad).
+// Head backward, 3 launches of fp32 FMAs (B <= 32 rows: 0.4 + 2.4 MFLOP of dgrad, the same of wgrad).  Work items of a launch:
+// weight-gradient elements one per thread; the dgrad rows by workgroups of 64 output columns x 8 waves, the waves striding the
+// contraction index (coalesced weight reads, B running sums per thread, one LDS reduction).
 // H1: gW4[c, j] = sum_b dl[b, c] g[b, j];  gb4[c] = sum_b dl[b, c];  da[b, j] = (sum_c dl[b, c] W4[c, j]) drop'(b, j) gelu'(a[b, j])
-template <typename T>
-__global__ void __launch_bounds__(256) tr_head_bwd1_kernel(const float* __restrict__ dl, const float* __restrict__ W4, const uint16_t* __restrict__ g16,
+template <typename T, int MAXB>
+__global__ void __launch_bounds__(512) tr_head_bwd1_kernel(const float* __restrict__ dl, const float* __restrict__ W4, const uint16_t* __restrict__ g16,
                                                            const uint16_t* __restrict__ a16, float* __restrict__ gW4, float* __restrict__ gb4,
                                                            float* __restrict__ da, int B, int C, int Dh, float p, uint64_t seed_arg) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int nW = C * Dh, nA = B * Dh;
+  extern __shared__ __attribute__((aligned(16))) float hb_smem[];      // [8][64] reduction + [MAXB][C] dlogits
+  float* red = hb_smem;
+  float* dls = hb_smem + 512;
+  const int nda = Dh / 64, tid = threadIdx.x;
+  if ((int)blockIdx.x < nda) {
+    for (int i = tid; i < MAXB * C; i += 512) dls[i] = i < B * C ? dl[i] : 0.f;
+    __syncthreads();
+    const int j = blockIdx.x * 64 + (tid & 63), wave = tid >> 6;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int c = wave; c < C; c += 8) {
+      const float w = W4[(size_t)c * Dh + j];
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) acc[b] += dls[b * C + c] * w;
+    }
+    const uint64_t seed = p > 0.f ? resolve_seed(seed_arg) : 0;
+    for (int b = 0; b < B; ++b) {
+      __syncthreads();
+      red[wave * 64 + (tid & 63)] = acc[b];
+      __syncthreads();
+      if (wave == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k * 64 + tid];
+        const int e = b * Dh + j;
+        if (p > 0.f) v *= dropout_factor(p, seed, (uint64_t)e);
+        da[e] = v * act_grad_rt(T::to_f32(a16[e]), VMC_ACT_GELU_ERF);
+      }
+    }
+    return;
+  }
+  const int i = ((int)blockIdx.x - nda) * 512 + tid;
+  const int nW = C * Dh;
   if (i < nW) {
     if (gW4 == nullptr) return;
     const int c = i / Dh, j = i - c * Dh;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) acc += dl[b * C + c] * T::to_f32(g16[b * Dh + j]);
     gW4[i] = acc;
-  } else if (i < nW + nA) {
-    const int e = i - nW, b = e / Dh, j = e - b * Dh;
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc += dl[b * C + c] * W4[c * Dh + j];
-    if (p > 0.f) acc *= dropout_factor(p, resolve_seed(seed_arg), (uint64_t)e);
-    da[e] = acc * act_grad_rt(T::to_f32(a16[e]), VMC_ACT_GELU_ERF);
-  } else if (i < nW + nA + C) {
+  } else if (i < nW + C) {
     if (gb4 == nullptr) return;
-    const int c = i - nW - nA;
+    const int c = i - nW;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) acc += dl[b * C + c];
     gb4[c] = acc;
   }
 }
 // H2: gW1[j, k] = sum_b da[b, j] pool16[b, k];  gb1[j] = sum_b da[b, j];  dpl[b, k] = sum_j da[b, j] W1[j, k]
-template <typename T>
-__global__ void __launch_bounds__(256) tr_head_bwd2_kernel(const float* __restrict__ da, const float* __restrict__ W1, const uint16_t* __restrict__ pool16,
+template <typename T, int MAXB>
+__global__ void __launch_bounds__(512) tr_head_bwd2_kernel(const float* __restrict__ da, const float* __restrict__ W1, const uint16_t* __restrict__ pool16,
                                                            float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ dpl, int B, int Dh,
                                                            int D) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int nW = Dh * D, nP = B * D;
+  extern __shared__ __attribute__((aligned(16))) float hb_smem[];      // [8][64] reduction + [MAXB][Dh] da
+  float* red = hb_smem;
+  float* das = hb_smem + 512;
+  const int ndp = D / 64, tid = threadIdx.x;
+  if ((int)blockIdx.x < ndp) {
+    for (int i = tid; i < MAXB * Dh; i += 512) das[i] = i < B * Dh ? da[i] : 0.f;
+    __syncthreads();
+    const int k = blockIdx.x * 64 + (tid & 63), wave = tid >> 6;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+#pragma unroll 4
+    for (int j = wave; j < Dh; j += 8) {
+      const float w = W1[(size_t)j * D + k];
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) acc[b] += das[b * Dh + j] * w;
+    }
+    for (int b = 0; b < B; ++b) {
+      __syncthreads();
+      red[wave * 64 + (tid & 63)] = acc[b];
+      __syncthreads();
+      if (wave == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += red[q * 64 + tid];
+        dpl[(size_t)b * D + k] = v;
+      }
+    }
+    return;
+  }
+  const int i = ((int)blockIdx.x - ndp) * 512 + tid;
+  const int nW = Dh * D;
   if (i < nW) {
     if (gW1 == nullptr) return;
     const int j = i / D, k = i - j * D;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) acc += da[b * Dh + j] * T::to_f32(pool16[b * D + k]);
     gW1[i] = acc;
-  } else if (i < nW + nP) {
-    const int e = i - nW, b = e / D, k = e - b * D;
-    float acc = 0.f;
-    for (int j = 0; j < Dh; ++j) acc += da[b * Dh + j] * W1[(size_t)j * D + k];
-    dpl[e] = acc;
-  } else if (i < nW + nP + Dh) {
+  } else if (i < nW + Dh) {
     if (gb1 == nullptr) return;
-    const int j = i - nW - nP;
+    const int j = i - nW;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) acc += da[b * Dh + j];
     gb1[j] = acc;
@@ -486,12 +539,19 @@ int tr_head_bwd(const float* dlogits, const vmc_tfam_head_params& Hd, const TrDi
                 hipStream_t s) {
   const int D = d.D, Dh = D / 2, B = d.B, C = d.C;
   const TrLayerWs wl = tr_lw(ws, d, d.L - 1);
-  const int n1 = C * Dh + B * Dh + C, n2 = Dh * D + B * D + Dh;
-  hipLaunchKernelGGL((tr_head_bwd1_kernel<T>), dim3((n1 + 255) / 256), dim3(256), 0, s, dlogits, Hd.w32_cls4, ws.g16, ws.a16, Hd.gw_cls4, Hd.gb_cls4, ws.da,
-                     B, C, Dh, p_mlp, seed);
-  VMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL((tr_head_bwd2_kernel<T>), dim3((n2 + 255) / 256), dim3(256), 0, s, ws.da, Hd.w32_cls1, ws.pool16, Hd.gw_cls1, Hd.gb_cls1, ws.dpl, B, Dh,
-                     D);
+  const int n1 = Dh / 64 + (C * Dh + C + 511) / 512, n2 = D / 64 + (Dh * D + Dh + 511) / 512;
+#define TR_HB(MB)                                                                                                                             \
+  do {                                                                                                                                        \
+    hipLaunchKernelGGL((tr_head_bwd1_kernel<T, MB>), dim3(n1), dim3(512), (512 + MB * C) * sizeof(float), s, dlogits, Hd.w32_cls4, ws.g16,     \
+                       ws.a16, Hd.gw_cls4, Hd.gb_cls4, ws.da, B, C, Dh, p_mlp, seed);                                                         \
+    hipLaunchKernelGGL((tr_head_bwd2_kernel<T, MB>), dim3(n2), dim3(512), (512 + MB * Dh) * sizeof(float), s, ws.da, Hd.w32_cls1, ws.pool16,   \
+                       Hd.gw_cls1, Hd.gb_cls1, ws.dpl, B, Dh, D);                                                                             \
+  } while (0)
+  if ((size_t)32 * C * sizeof(float) > 60 * 1024) return VMC_E_SHAPE;      // the dlogits rows of H1 sit in LDS
+  if (B <= 8) TR_HB(8);
+  else if (B <= 16) TR_HB(16);
+  else TR_HB(32);
+#undef TR_HB
   VMC_CHECK_LAUNCH();
   if (D == 768)
     hipLaunchKernelGGL((tr_head_bwd3_kernel<768>), dim3(B + 1), dim3(256), 0, s, ws.pooled32, ws.dpl, Hd.cls_ln_g, wl.dx3, Hd.g_cls_ln_g, Hd.g_cls_ln_b, B, d.T,
@@ -527,8 +587,11 @@ struct TrWgradGroup {
 template <typename T>
 __global__ void __launch_bounds__(512) tr_wgrad_group_kernel(const TrWgradGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bid = blockIdx.x;
-  if (bid < g.total_tiles) {
+  // the LayerNorm parameter-gradient blocks come FIRST: they are short, and the grid (240 + 36 workgroups at one per CU) does not
+  // fit one resident round -- queued last they would start a second round behind the 256 x 128 tiles
+  const int n_ln = g.nln * (g.D / 64);
+  const int bid = (int)blockIdx.x - n_ln;
+  if (bid >= 0) {
     int i = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k)
@@ -540,7 +603,7 @@ __global__ void __launch_bounds__(512) tr_wgrad_group_kernel(const TrWgradGroup 
     return;
   }
   // LayerNorm parameter gradients: 64 columns per workgroup, the 8 waves stride the token rows
-  const int idx = bid - g.total_tiles, cbs = g.D / 64;
+  const int idx = blockIdx.x, cbs = g.D / 64;
   const TrLnProb lp = g.ln[idx / cbs];
   const int col = (idx % cbs) * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
   float ag = 0.f, ab = 0.f;

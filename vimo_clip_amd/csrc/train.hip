@@ -78,7 +78,7 @@ extern "C" int vmc_distill_loss(const float* student, const float* teacher, floa
 // l = (1-y) x + (1 + (w-1) y) (log1p(exp(-|x|)) + max(-x, 0));  dl/dx = (1-y) - (1 + (w-1) y) (1 - sigmoid(x))
 #define BCE_BLOCKS 64
 __global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ part,
-                                                  float* __restrict__ dx, int n, float pw) {
+                                                  float* __restrict__ dx, int n, float pw, float* __restrict__ loss_out) {
   __shared__ float sm[4];
   float acc = 0.f;
   const float invn = 1.0f / (float)n;
@@ -95,7 +95,11 @@ __global__ void __launch_bounds__(256) bce_kernel(const float* __restrict__ x, c
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  if (threadIdx.x == 0) {
+    const float tot = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (loss_out != nullptr) loss_out[0] = tot * invn;      // single-workgroup launch (small n): no second pass
+    else part[blockIdx.x] = tot;
+  }
 }
 
 extern "C" int vmc_bce_loss(const float* logits, const float* targets, float* loss, float* dlogits, int n, float pos_weight,
@@ -105,7 +109,12 @@ extern "C" int vmc_bce_loss(const float* logits, const float* targets, float* lo
   hipStream_t s = (hipStream_t)stream;
   int blocks = (n + 255) / 256;
   if (blocks > BCE_BLOCKS) blocks = BCE_BLOCKS;
-  hipLaunchKernelGGL(bce_kernel, dim3(blocks), dim3(256), 0, s, logits, targets, (float*)workspace, dlogits, n, pos_weight);
+  if (n <= 8192) {      // a TFAM batch of a few clips x 140 classes: one workgroup, one launch (the launch count is the cost there)
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, s, logits, targets, (float*)workspace, dlogits, n, pos_weight, loss);
+    VMC_CHECK_LAUNCH();
+    return 0;
+  }
+  hipLaunchKernelGGL(bce_kernel, dim3(blocks), dim3(256), 0, s, logits, targets, (float*)workspace, dlogits, n, pos_weight, (float*)nullptr);
   VMC_CHECK_LAUNCH();
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, loss, blocks, 1.0f / (float)n);
   VMC_CHECK_LAUNCH();
@@ -177,20 +186,30 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     lr = hyper[0]; step_size = hyper[1]; inv_sqrt_bc2 = hyper[2]; gscale = hyper[3];
   }
   const size_t n4 = n >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    float4 pp = ((float4*)p)[i];
-    const float4 gg = ((const float4*)g)[i];
-    float4 mm = ((float4*)m)[i], vv = ((float4*)v)[i];
-    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // two float4 of each of the four streams in flight per thread: a grid of 2 workgroups per CU (what the backward-overlapped
+  // step launches, so that the update never takes the wave slots the backward's workgroups need) still covers the HBM latency
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const size_t i1 = i0 + stride;
+    const bool two = i1 < n4;
+    float4 pp[2], gg[2], mm[2], vv[2];
+    pp[0] = ((float4*)p)[i0]; gg[0] = ((const float4*)g)[i0]; mm[0] = ((float4*)m)[i0]; vv[0] = ((float4*)v)[i0];
+    if (two) { pp[1] = ((float4*)p)[i1]; gg[1] = ((const float4*)g)[i1]; mm[1] = ((float4*)m)[i1]; vv[1] = ((float4*)v)[i1]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gr = G[j] * gscale;
-      if (decoupled) P[j] *= (1.0f - lr * wd); else gr += wd * P[j];
-      M[j] = b1 * M[j] + (1.0f - b1) * gr;
-      V[j] = b2 * V[j] + (1.0f - b2) * gr * gr;
-      P[j] -= step_size * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float* P = &pp[u].x; const float* G = &gg[u].x; float* M = &mm[u].x; float* V = &vv[u].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gr = G[j] * gscale;
+        if (decoupled) P[j] *= (1.0f - lr * wd); else gr += wd * P[j];
+        M[j] = b1 * M[j] + (1.0f - b1) * gr;
+        V[j] = b2 * V[j] + (1.0f - b2) * gr * gr;
+        P[j] -= step_size * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
+      }
+      const size_t i = u ? i1 : i0;
+      ((float4*)p)[i] = pp[u]; ((float4*)m)[i] = mm[u]; ((float4*)v)[i] = vv[u];
     }
-    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t k = (n4 << 2) + threadIdx.x;
@@ -250,9 +269,13 @@ extern "C" int vmc_train_tick(void* state, float* hyper, float beta1, float beta
 
 extern "C" int vmc_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
                                  float eps, float weight_decay, int decoupled_wd, void* stream) {
-  if (!p || !g || !m || !v || !hyper || n == 0) return VMC_E_ARG;
+  return vmc_adam_step_dev_bg(p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay, decoupled_wd, 256 * 8, stream);
+}
+extern "C" int vmc_adam_step_dev_bg(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
+                                    float eps, float weight_decay, int decoupled_wd, int max_workgroups, void* stream) {
+  if (!p || !g || !m || !v || !hyper || n == 0 || max_workgroups <= 0) return VMC_E_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)hyper) & 15) return VMC_E_ALIGN;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256, max_workgroups)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
                      beta2, eps, weight_decay, decoupled_wd, 0.f, 0.f, 0.f, hyper);
   VMC_CHECK_LAUNCH();
   return 0;

@@ -122,3 +122,28 @@ def cross_entropy_loss(predictions, targets):
 def reconstruction_loss(reconstruction, input):  # noqa: A002  (reference signature)
     """losses.py:70-81."""
     raise NotImplementedError
+
+
+def loss_and_grad(criterion, logits, targets):
+    """(loss, d loss / d logits) of a mean-reduced criterion of this module WITHOUT autograd nodes: the loss kernels produce the
+    gradient in the same launch, and ``logits.backward(dlogits)`` is what ``loss.backward()`` computes (implicit upstream gradient 1)
+    minus two launches (autograd's ones fill, the scaling by it) -- the training loops of TFAM/train_and_eval.py:81-83 spelled for a
+    launch-bound step.  criterion: bce_with_logits_loss or cross_entropy_loss."""
+    x = logits.detach().contiguous().float()
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    if criterion is bce_with_logits_loss:
+        y = targets.contiguous().float()
+        if x.shape != y.shape:
+            raise ValueError(f"Target size ({tuple(y.shape)}) must be the same as input size ({tuple(x.shape)})")
+        ws = torch.empty(64, dtype=torch.float32, device=x.device)
+        check(lib.vmc_bce_loss(ptr(x), ptr(y), ptr(loss), ptr(dx), x.numel(), -1.0, ptr(ws), 256, stream()), "bce_loss")
+    elif criterion is cross_entropy_loss:
+        rows, C = x.shape
+        tidx, tprob = (None, targets.contiguous().float()) if targets.is_floating_point() else (targets.contiguous().to(torch.int64), None)
+        ws = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.vmc_cross_entropy_loss(ptr(x), ptr(tidx), ptr(tprob), ptr(loss), ptr(dx), rows, C, ptr(ws), rows * 4, stream()),
+              "cross_entropy_loss")
+    else:
+        raise ValueError("loss_and_grad: criterion must be bce_with_logits_loss or cross_entropy_loss")
+    return loss, dx.view(logits.shape)

@@ -11,6 +11,7 @@ flat gradient buffer in large buckets (parallel.py).  Mirrors ``torch.optim.Adam
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -116,23 +117,113 @@ class FusedAdam:
             raise IndexError("more dropout call sites per step than FusedAdam.N_SEEDS")
         return (1 << 63) | (self.dev_state.data_ptr() + 8 * (2 + i))
 
+    # ---- optimiser step overlapped with the backward ----------------------------------------------------------------------
+    def enable_backward_overlap(self, groups):
+        """groups: lists of parameters, each a contiguous run of the arena, whose gradients become final TOGETHER during the
+        backward (a TFAM layer; the classifier head).  ``group_ready(i)`` -- called by the backward the moment group i's
+        gradients have been enqueued (tfam_train.TfamTrainFn.backward) -- then enqueues that range's AdamW update and the refresh
+        of its 16-bit compute copies on a side stream, beside the rest of the backward: the update is HBM-bound (28 B per
+        parameter), the backward of the layers below is a chain of latency-bound launches that read none of the updated
+        buffers.  ``step()`` afterwards updates whatever is left and joins the side stream.  Same arithmetic, element for
+        element, as one whole-arena step.  Only for a single process without gradient clipping (both need the complete
+        gradient first); ``step(grad_scale != 1)`` / ``max_grad_norm`` after a group was already updated raise."""
+        a = self.arena
+        index = {id(p): i for i, p in enumerate(a.params)}
+        ranges = []
+        for g in groups:
+            idx = sorted(index[id(p)] for p in g if id(p) in index)
+            if not idx:
+                continue
+            if idx != list(range(idx[0], idx[-1] + 1)):
+                raise ValueError("enable_backward_overlap: a group must be a contiguous run of the arena's parameters")
+            lo = a.offsets[idx[0]]
+            hi = a.offsets[idx[-1] + 1] if idx[-1] + 1 < len(a.params) else a.numel
+            ranges.append((lo, hi, frozenset(id(a.params[i]) for i in idx)))
+        covered = sorted((lo, hi) for lo, hi, _ in ranges)
+        rest, pos = [], 0
+        for lo, hi in covered:
+            if lo < pos:
+                raise ValueError("enable_backward_overlap: groups overlap")
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = hi
+        if pos < a.numel:
+            rest.append((pos, a.numel))
+        rest_ids = frozenset(id(p) for p in a.params) - frozenset().union(*[r[2] for r in ranges]) if ranges else frozenset(id(p) for p in a.params)
+        self._ov = {"ranges": ranges, "rest": rest, "rest_ids": rest_ids, "done": [False] * len(ranges),
+                    "stream": torch.cuda.Stream(device=a.flat_param.device, priority=int(os.environ.get("VMC_ADAM_SIDE_PRIO", "0"))),
+                    "used": False}
+        return self
+
+    def disable_backward_overlap(self):
+        self._ov = None
+
+    def _open_step(self):
+        if not getattr(self, "_step_open", False):
+            if getattr(self, "dev_state", None) is None:
+                self.step_count += 1                   # device-state mode: tick() already advanced t
+            self._step_open = True
+
+    BG_WORKGROUPS = int(os.environ.get("VMC_ADAM_BG_WGS", "512"))      # side-stream update: 2 workgroups of 256 threads per CU
+
+    def _update_range(self, lo, hi, grad_scale=1.0, background=False):
+        a, n = self.arena, hi - lo
+        if n <= 0:
+            return
+        p, g, m, v = a.flat_param[lo:hi], a.flat_grad[lo:hi], self.m[lo:hi], self.v[lo:hi]
+        if getattr(self, "dev_state", None) is not None:
+            check(lib.vmc_adam_step_dev_bg(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(self.dev_hyper), float(self.betas[0]), float(self.betas[1]),
+                                           float(self.eps), float(self.weight_decay), int(self.decoupled),
+                                           self.BG_WORKGROUPS if background else 2048, stream()), "adam_step_dev")
+        else:
+            check(lib.vmc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, float(self.param_groups[0]["lr"]), float(self.betas[0]),
+                                    float(self.betas[1]), float(self.eps), float(self.weight_decay), int(self.decoupled), self.step_count,
+                                    float(grad_scale), stream()), "adam_step")
+
+    def group_ready(self, i: int):
+        """The gradients of overlap group i are complete (enqueued on the current stream): update it now, beside the backward."""
+        ov = getattr(self, "_ov", None)
+        if ov is None or i >= len(ov["ranges"]) or ov["done"][i]:
+            return
+        lo, hi, ids = ov["ranges"][i]
+        self._open_step()
+        side = ov["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._update_range(lo, hi, background=True)
+            from . import autograd_ops
+            autograd_ops.weights.refresh(owner=(id(self), i), param_ids=ids)
+        ov["done"][i] = ov["used"] = True
+
     def step(self, grad_scale: float = 1.0, max_grad_norm=None):
         a = self.arena
-        if getattr(self, "dev_state", None) is not None:      # device-state mode: tick() already advanced t
-            if max_grad_norm is not None:
-                raise ValueError("gradient clipping needs a host read of the norm: not available in device-state mode")
-            check(lib.vmc_adam_step_dev(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, ptr(self.dev_hyper),
-                                        float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                                        int(self.decoupled), stream()), "adam_step_dev")
-            invalidate_weight_copies(self)
+        dev_mode = getattr(self, "dev_state", None) is not None
+        ov = getattr(self, "_ov", None)
+        if dev_mode and max_grad_norm is not None:
+            raise ValueError("gradient clipping needs a host read of the norm: not available in device-state mode")
+        if ov is not None and ov["used"]:
+            # some ranges were updated during the backward: finish the others on this stream, then join
+            if max_grad_norm is not None or grad_scale != 1.0:
+                raise ValueError("backward-overlapped optimiser steps cannot be combined with grad_scale / max_grad_norm")
+            from . import autograd_ops
+            for i, (lo, hi, ids) in enumerate(ov["ranges"]):
+                if not ov["done"][i]:
+                    self._update_range(lo, hi)
+                    autograd_ops.weights.refresh(owner=(id(self), i), param_ids=ids)
+            for lo, hi in ov["rest"]:
+                self._update_range(lo, hi)
+            if ov["rest"] and ov["rest_ids"]:
+                autograd_ops.weights.refresh(owner=(id(self), "rest"), param_ids=ov["rest_ids"])
+            torch.cuda.current_stream().wait_stream(ov["stream"])
+            ov["done"] = [False] * len(ov["ranges"])
+            ov["used"] = False
+            self._step_open = False
             return
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
             grad_scale = clipped_grad_scale(float(a.grad_norm().item()), grad_scale, max_grad_norm)
-        self.step_count += 1
-        lr = self.param_groups[0]["lr"]
-        check(lib.vmc_adam_step(ptr(a.flat_param), ptr(a.flat_grad), ptr(self.m), ptr(self.v), a.numel, float(lr),
-                                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                                int(self.decoupled), self.step_count, float(grad_scale), stream()), "adam_step")
+        self._open_step()
+        self._update_range(0, a.numel, grad_scale)
+        self._step_open = False
         invalidate_weight_copies(self)
 
     def state_dict(self):

@@ -220,6 +220,9 @@ class TfamTrainFn(torch.autograd.Function):
                                     int(sarr[SEEDS_PER_LAYER * L]) if sarr is not None else 0, dt(dt16), stream()), "tfam_head_bwd")
         c = model.classifier
         _report((c[4].weight, c[4].bias, c[1].weight, c[1].bias, c[0].weight, c[0].bias))
+        done = getattr(model, "grad_group_callback", None)      # e.g. FusedAdam.group_ready: the optimiser step of a finished group
+        if done is not None:                                     # runs beside the rest of the backward (group L = the classifier)
+            done(L)
         for l in range(L - 1, -1, -1):
             check(lib.vmc_tfam_layer_bwd(ptr(mask), ptr(mask_kv) if cross else None, layers, l, ptr(ws), nbytes, *dims, p_drop,
                                          seed_at(SEEDS_PER_LAYER * l), dt(dt16), stream()), "tfam_layer_bwd")
@@ -231,6 +234,8 @@ class TfamTrainFn(torch.autograd.Function):
                         ca.in_proj_weight, ca.in_proj_bias]
             rep += [layer.norm_self.weight, layer.norm_self.bias, sa.out_proj.weight, sa.out_proj.bias, sa.in_proj_weight, sa.in_proj_bias]
             _report(rep)
+            if done is not None:
+                done(l)
         grads = tuple((fresh.get(id(p)) if p.requires_grad and getattr(p, "_vmc_grad", None) is None else None) for p in ctx.params)
         ctx.ws = None
         return (None,) * 9 + grads
