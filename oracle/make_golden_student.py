@@ -12,9 +12,14 @@ TFAM/data/dataset.py, the classes are compiled from the file's AST -- nothing el
   ``io.read_video`` returns stored frame arrays.  Every index / pad / clamp decision is the reference's code.  Embedding rows
   and flow frames carry their own index as value, so the outputs ARE the gather indices (-1 = all-zero padding frame).
 
-Still unpinnable here, and said so in DESIGN.md: ``FlowStudentModel.__init__/forward`` as a whole (``clip.load`` fetches
-weights by name; ``to_pil_image`` / torchvision transforms are absent) -- its composition is restated in oracle/student.py and
-its ViT arithmetic is pinned through transformers.CLIPModel (tests/golden/vit.npz).
+* ``FlowStudentModel`` (models/student_model.py:38-98), round 3: ``__init__`` and ``forward`` run as written, with stand-ins for the
+  three things that do not exist offline: ``clip.load(name, device)`` returns (a model whose ``.visual`` is the oracle ViT as an
+  ``nn.Module`` with seeded weights and ``.output_dim``, a preprocess object whose ``.transforms`` is [u8 frame -> normalised
+  tensor]); ``transforms.Compose`` chains callables; ``to_pil_image`` is bound to the float -> u8 wrap the oracle ascribes to it
+  (``vit.to_pil_wrap_u8``).  That pins the COMPOSITION -- view(B*T) -> per-frame preprocess -> stack -> visual encoder ->
+  view(B, T, -1) -> ResidualMLP -> mean(dim=1) -> classification_head(.float()) and the three returned tensors -- against
+  oracle/student.py:student_forward.  What remains unpinnable: torchvision's ``to_pil_image`` itself (its float handling is
+  restated, not run) and the weights ``clip.load`` would fetch by name.
 
     python -m oracle.make_golden_student        # writes tests/golden/student.npz
 """
@@ -38,6 +43,9 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 MLP_CASES = [dict(name="e32", E=32, B=3, T=5, alpha=0.1, seed=71), dict(name="e512", E=512, B=2, T=16, alpha=0.1, seed=72),
              dict(name="e768_a05", E=768, B=1, T=4, alpha=0.5, seed=73)]
+# FlowStudentModel.forward composition (models/student_model.py:61-98) on tiny geometries; alpha != default in one case
+FWD_CASES = [dict(name="tiny32", model="ViT-tiny/32", B=3, T=5, C=140, alpha=0.1, seed=81),
+             dict(name="tiny14_a03", model="ViT-tiny/14", B=2, T=4, C=20, alpha=0.3, seed=82)]
 # video lengths (embedding rows) and flow lengths; real data has T_flow = T - 1, the others exercise the clamps (:108-113)
 VIDEOS = [("a.mp4", 12, 11), ("b.mp4", 5, 4), ("c.mp4", 1, 0), ("d.mp4", 0, 0), ("e.mp4", 7, 3), ("f.mp4", 30, 29), ("g.mp4", 9, 12)]
 SEQ_LENS = [2, 4, 5, 17, 30]
@@ -82,6 +90,60 @@ def main():
         (m(xr) * g).sum().backward()
         out[f"mlp/{c['name']}/dx"] = xr.grad.numpy()
         out[f"mlp/{c['name']}/dfc1w"] = m.fc1.weight.grad[:8].numpy()          # first 8 rows: keeps the fixture small
+
+    # ---------------- FlowStudentModel: __init__ + forward as written, stand-ins for clip.load / Compose / to_pil_image -------------
+    from oracle import vit as ovit
+    for c in FWD_CASES:
+        sd = synth.student_state_dict(c["model"], c["seed"], num_classes=c["C"])
+        R, heads, E = synth.VIT_GEOMETRY[c["model"]][0], synth.VIT_GEOMETRY[c["model"]][4], synth.VIT_GEOMETRY[c["model"]][5]
+
+        class _Visual(torch.nn.Module):
+            output_dim = E
+
+            def forward(self, pix):
+                return ovit.vit_forward(sd, pix, heads, prefix="visual_encoder.")
+
+        class _ClipModel:
+            visual = _Visual()
+
+            def float(self):
+                return self
+
+        class _Preprocess:
+            transforms = [lambda fr_u8: ovit.normalize_u8(fr_u8.unsqueeze(0))[0]]
+
+        class _Clip:
+            @staticmethod
+            def load(name, device=None):
+                assert name == c["model"]
+                return _ClipModel(), _Preprocess()
+
+        class _Transforms:
+            @staticmethod
+            def Compose(fns):
+                def run(x):
+                    for f in fns:
+                        x = f(x)
+                    return x
+                return run
+
+        ns = {"torch": torch, "nn": torch.nn, "clip": _Clip, "transforms": _Transforms, "to_pil_image": ovit.to_pil_wrap_u8}
+        RefMLP2, RefStudent = _ast_classes(os.path.join(REF, "models", "student_model.py"), ["ResidualMLP", "FlowStudentModel"], ns)
+        m = RefStudent(clip_model_name=c["model"], device="cpu", num_classes=c["C"], alpha=c["alpha"])
+        assert isinstance(m.residual_mlp, RefMLP2) and m.classification_head[0].weight.shape == (E // 2, E)
+        own = {k: v for k, v in sd.items() if not k.startswith("visual_encoder.")}
+        missing = m.load_state_dict(own, strict=False)            # the stand-in encoder holds its weights outside the module tree
+        assert not missing.unexpected_keys and not missing.missing_keys, missing
+        vids = synth.randint_u8(c["seed"], "vids", (c["B"], c["T"], 3, R, R))
+        with torch.no_grad():
+            emb, emb_d, logits = m(vids)
+        o_emb, o_emb_d, o_logits = student.student_forward(sd, vids, heads, alpha=c["alpha"], wrap_quirk=True)
+        for a, b, nm in ((emb, o_emb, "emb"), (emb_d, o_emb_d, "emb_distill"), (logits, o_logits, "logits")):
+            err = (a - b).abs().max().item()
+            assert a.shape == b.shape and err < 1e-5, (c["name"], nm, err)
+        out[f"fwd/{c['name']}/emb"], out[f"fwd/{c['name']}/emb_distill"], out[f"fwd/{c['name']}/logits"] = emb.numpy(), emb_d.numpy(), logits.numpy()
+        print("  student fwd", c["name"], "oracle-vs-reference-class max abs", max((a - b).abs().max().item() for a, b in
+                                                                                 ((emb, o_emb), (emb_d, o_emb_d), (logits, o_logits))))
 
     # ---------------- dataset.py ----------------
     from vimo_clip_amd import h5lite

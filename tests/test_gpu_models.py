@@ -130,6 +130,26 @@ def _student(name, seed, dtype):
     return m, sd
 
 
+def test_student_forward_vs_reference_class_run(golden):
+    """a5: FlowStudentModel.forward on the GPU against tests/golden/student.npz fwd/* -- outputs of the reference's own class
+    (models/student_model.py:38-98, compiled from its AST, clip.load / Compose / to_pil_image bound to stand-ins:
+    oracle/make_golden_student.py).  f16: 1e-3 * max(1, |ref|max) as the encoder tests."""
+    from oracle import make_golden_student as mgs
+    from vimo_clip_amd.models import FlowStudentModel
+    for c in mgs.FWD_CASES:
+        m = FlowStudentModel(c["model"], device="cuda", num_classes=c["C"], alpha=c["alpha"], compute_dtype=torch.float16)
+        m.load_state_dict(synth.student_state_dict(c["model"], c["seed"], num_classes=c["C"]), strict=True)
+        R = synth.VIT_GEOMETRY[c["model"]][0]
+        vids = synth.randint_u8(c["seed"], "vids", (c["B"], c["T"], 3, R, R))
+        with torch.no_grad():
+            outs = m.eval()(vids.cuda())
+        for got, key in zip(outs, ("emb", "emb_distill", "logits")):
+            ref = torch.from_numpy(golden["student"][f"fwd/{c['name']}/{key}"])
+            err = (got.float().cpu() - ref).abs().max().item()
+            print(f"student fwd {c['name']} {key}: max abs err {err:.3e} (|ref|max {ref.abs().max():.2f})")
+            assert got.shape == ref.shape and err <= 1e-3 * max(1.0, ref.abs().max().item()), (c["name"], key, err)
+
+
 @pytest.mark.parametrize("name,B,T", [("ViT-tiny/32", 3, 5), ("ViT-B/32", 2, 4)])
 def test_student_forward_vs_oracle(name, B, T):
     R, H = synth.VIT_GEOMETRY[name][0], synth.VIT_GEOMETRY[name][4]

@@ -75,3 +75,20 @@ def test_oracle_residual_mlp_matches_the_reference_class(golden):
         sd = {"residual_mlp.fc1.weight": w1, "residual_mlp.fc1.bias": b1, "residual_mlp.fc2.weight": w2, "residual_mlp.fc2.bias": b2}
         y = ostudent.residual_mlp(sd, x, c["alpha"])
         assert np.abs(y.numpy() - g[f"mlp/{c['name']}/y"]).max() < 1e-6
+
+
+def test_oracle_student_forward_equals_the_reference_class_run(golden):
+    """student.npz fwd/*: FlowStudentModel.__init__/forward (models/student_model.py:38-98) compiled from the reference's AST and RUN
+    with stand-ins for clip.load / transforms.Compose / to_pil_image (oracle/make_golden_student.py): the composition
+    view -> preprocess -> encoder -> view -> ResidualMLP -> mean(dim=1) -> head of oracle/student.py:student_forward is pinned."""
+    from vimo_clip_amd import synth
+    g = golden["student"]
+    for c in mgs.FWD_CASES:
+        sd = synth.student_state_dict(c["model"], c["seed"], num_classes=c["C"])
+        R, heads = synth.VIT_GEOMETRY[c["model"]][0], synth.VIT_GEOMETRY[c["model"]][4]
+        vids = synth.randint_u8(c["seed"], "vids", (c["B"], c["T"], 3, R, R))
+        outs = ostudent.student_forward(sd, vids, heads, alpha=c["alpha"], wrap_quirk=True)
+        for got, key in zip(outs, ("emb", "emb_distill", "logits")):
+            ref = torch.from_numpy(g[f"fwd/{c['name']}/{key}"])
+            assert got.shape == ref.shape and (got - ref).abs().max().item() <= 1e-5, (c["name"], key)
+        assert (outs[0] - outs[1]).abs().max().item() > 1e-3          # fc2 is not zero here: the distillation branch differs
