@@ -388,3 +388,75 @@ def test_fused_scratch_of_captured_forwards_is_never_freed():
         pack.workspace(2, T, 15, True, 1)
     assert pack.workspace(2, 16, 15, True, 0).data_ptr() == ws0.data_ptr()
     assert (2, 16, 15, True, 0) in pack._pinned and len(pack._ws) <= pack.MAX_UNPINNED + 1
+
+
+def _ddp_graph_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vimo_clip_amd import autograd_ops, parallel
+    from vimo_clip_amd.graphs import GraphedTrainStep
+    from vimo_clip_amd.losses import bce_with_logits_loss, loss_and_grad
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    dist.init_process_group("gloo")                        # two ranks share the one GPU of the box: gloo instead of RCCL
+    try:
+        D, H, L, FF, C, B = 512, 8, 2, 512, 140, 4           # the fused training chains' shape set (d_model 512, T = 16)
+        res = {}
+        for mode in ("plain", "all_reduce", "rs_ag"):
+            autograd_ops.grad_ready_hooks.clear()
+            m = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.1, mlp_dropout=0.1, device="cuda").cuda().train()
+            m.load_state_dict(synth.tfam_state_dict(D, H, L, FF, C, 9), strict=True)
+            arena = GradArena(m.used_parameters())
+            opt = FusedAdam(arena, lr=1e-3, weight_decay=0.1, decoupled=True)
+            opt.enable_device_state(base_seed=77 + rank)
+            m.use_device_seeds(opt)
+            red = parallel.GradientAllReducer(arena.flat_grad, bucket_bytes=256 * 1024, exchange="all_reduce" if mode == "plain" else mode)
+
+            def fwd_bwd(rgb, mot, y):
+                opt.tick()
+                out = m(rgb, mot)
+                loss, dl = loss_and_grad(bce_with_logits_loss, out, y)
+                out.backward(dl)
+                return loss, out.detach()
+            stepper = None if mode == "plain" else GraphedTrainStep(fwd_bwd, opt, exchange=red.all_reduce, opt_fn=opt.step)
+            for step in range(4):
+                Tn = 16 if step % 2 else 12                   # two shapes -> two forward/backward graphs, one optimiser graph
+                rgb = synth.normal(100 * rank + step, "r", (B, Tn, D)).cuda()
+                mot = synth.normal(100 * rank + step, "m", (B, Tn - 1, D)).cuda()
+                y = synth.multi_hot_labels(100 * rank + step, "y", B, C).cuda()
+                if stepper is None:
+                    fwd_bwd(rgb, mot, y)
+                    opt.sync_hyper(grad_scale=red.all_reduce())
+                    opt.step()
+                else:
+                    stepper(rgb, mot, y)
+            torch.cuda.synchronize()
+            res[mode] = (arena.flat_param.detach().cpu().clone(), None if stepper is None else (len(stepper._graphs), stepper._opt_graph is not None))
+        ok = all(torch.equal(res["plain"][0], res[k][0]) for k in ("all_reduce", "rs_ag"))
+        q.put((rank, ok, res["all_reduce"][1], res["rs_ag"][1], float(res["plain"][0].abs().sum()), int(opt.dev_state[0].item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_graph_data_parallel_step_two_ranks_one_gpu():
+    """under data parallelism the small-batch step is forward/backward graph -> gradient exchange -> optimiser
+    graph (graphs.GraphedTrainStep(exchange=, opt_fn=)) instead of the host-bound eager step.  Two ranks with different data and
+    dropout on, four steps over two batch shapes: parameters bit-identical to the eager device-state step, for both exchanges."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res                        # two-graph == plain, bit for bit, both exchanges
+    assert res[0][2] == res[0][3] == (2, True), res
+    assert res[0][4] == res[1][4] and res[0][5] == 4          # replicas identical; capture runs left no trace in the step count

@@ -102,6 +102,109 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _EagerGraph:
+    """Stand-in for graphs.GraphedCallable on a machine without a GPU: same interface (warm-up run, then call = run)."""
+
+    def __init__(self, fn, *example_inputs, warmup=1):
+        self.fn = fn
+        for _ in range(warmup):
+            fn(*example_inputs)
+
+    def __call__(self, *inputs):
+        return self.fn(*inputs)
+
+
+def _two_graph_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from vimo_clip_amd import autograd_ops, parallel
+    from vimo_clip_amd.graphs import GraphedTrainStep
+    parallel.init_from_env("gloo")
+    try:
+        class _Arena:
+            pass
+
+        class _Opt:           # the attribute surface GraphedTrainStep and the trainer use of optim.FusedAdam (device-state mode)
+            def __init__(self, n):
+                self.arena = _Arena()
+                g = torch.Generator().manual_seed(7)
+                self.arena.flat_param = torch.randn(n, generator=g)
+                self.arena.flat_grad = torch.zeros(n)
+                self.m, self.v = torch.zeros(n), torch.zeros(n)
+                self.dev_state = torch.zeros(4, dtype=torch.int64)
+                self.dev_hyper = torch.tensor([0.1, 0.0, 0.0, 1.0])
+                self.step_count = 0
+
+            def sync_hyper(self, grad_scale=1.0):
+                self.dev_hyper[3] = grad_scale
+
+            def tick(self):
+                self.dev_state[0] += 1
+
+            def step(self):   # momentum SGD on the exchanged gradient, scaled by the device-resident factor
+                self.m.mul_(0.9).add_(self.arena.flat_grad * self.dev_hyper[3])
+                self.arena.flat_param.sub_(self.dev_hyper[0] * self.m)
+
+        def run(two_graph, exchange):
+            opt = _Opt(50_000)
+            red = parallel.GradientAllReducer(opt.arena.flat_grad, bucket_bytes=64 * 1024, exchange=exchange)
+            fired = []
+            hook = lambda p: fired.append(p)                      # noqa: E731
+            autograd_ops.grad_ready_hooks.append(hook)
+
+            def fwd_bwd(x):
+                opt.tick()
+                opt.arena.flat_grad.copy_(torch.sin(opt.arena.flat_param * (rank + 1)) * x.sum())     # rank-dependent "gradient"
+                for h in list(autograd_ops.grad_ready_hooks):
+                    h("p")
+                return opt.arena.flat_grad[:4].clone()
+            try:
+                stepper = GraphedTrainStep(fwd_bwd, opt, exchange=red.all_reduce, opt_fn=opt.step, graph_factory=_EagerGraph) if two_graph else None
+                for i in range(4):
+                    x = torch.full((3 if i % 2 else 5,), float(i + 1))     # two batch shapes -> two forward/backward "graphs"
+                    if two_graph:
+                        stepper(x)
+                    else:
+                        fwd_bwd(x)
+                        opt.sync_hyper(grad_scale=red.all_reduce())
+                        opt.step()
+                        opt.step_count += 1
+            finally:
+                autograd_ops.grad_ready_hooks.remove(hook)
+            return opt, len(fired), stepper
+        ref, fired_ref, _ = run(False, "all_reduce")
+        assert fired_ref == 4
+        for ex in parallel.GradientAllReducer.EXCHANGES:
+            o, fired, st = run(True, ex)
+            assert len(st._graphs) == 2 and st._opt_graph is not None
+            assert fired == 4, fired                               # silenced during the 3 warm-up / capture runs, live in the 4 steps
+            assert o.step_count == ref.step_count == 4 and int(o.dev_state[0]) == 4          # capture runs were undone
+            assert torch.equal(o.arena.flat_param, ref.arena.flat_param) and torch.equal(o.m, ref.m), ex
+        both = [torch.empty_like(ref.arena.flat_param) for _ in range(world)]
+        dist.all_gather(both, ref.arena.flat_param)
+        assert torch.equal(both[0], both[1])                       # replicas stay identical
+        q.put((rank, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_graph_data_parallel_step_equals_the_plain_step_gloo_world2():
+    """GraphedTrainStep(exchange=..., opt_fn=...) -- forward/backward graph, gradient exchange, optimiser graph --
+    must give the parameters of the plain step (forward/backward, exchange, optimiser) bit for bit, with both exchange algorithms,
+    over several batch shapes; the warm-up / capture runs must leave no trace (graph stand-in: eager callables, no GPU here)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -200,12 +200,17 @@ class ModelTrainer:
         self.reducer = parallel.GradientAllReducer(self.arena.flat_grad).attach(self.arena)   # buckets go out during the backward
         self._graphed_eval = GraphedEvalForward(model, config) if getattr(config, "use_graphs", False) else None
         self._graphed_train = None
-        if getattr(config, "use_graphs", False) and world == 1:
-            # captured training steps: step count / lr / dropout seeds in device memory (optim.FusedAdam.enable_device_state)
+        if getattr(config, "use_graphs", False):
+            # captured training steps: step count / lr / dropout seeds in device memory (optim.FusedAdam.enable_device_state).
+            # One process: the whole step is one graph.  Data parallel: forward + backward graph, the gradient exchange, optimiser graph.
             from ..graphs import GraphedTrainStep
-            self.optimizer.enable_device_state(base_seed=config.seed)
+            self.optimizer.enable_device_state(base_seed=config.seed if world == 1 else config.seed * 1000 + rank)
             model.use_device_seeds(self.optimizer)
-            self._graphed_train = GraphedTrainStep(self._device_state_step, self.optimizer)
+            if world == 1:
+                self._graphed_train = GraphedTrainStep(self._device_state_step, self.optimizer)
+            else:
+                self._graphed_train = GraphedTrainStep(self._device_state_fwd_bwd, self.optimizer, exchange=self.reducer.all_reduce,
+                                                       opt_fn=self.optimizer.step)
         if world == 1 and os.environ.get("VMC_ADAM_OVERLAP", "0") == "1":
             # AdamW of a finished layer on a side stream beside the backward of the layers below it.  Bit-identical, but measured
             # SLOWER on MI355X (captured B = 8 step 0.88 -> 0.95-1.01 ms: the fork / join edges of a multi-stream hipGraph cost more
@@ -224,6 +229,15 @@ class ModelTrainer:
         loss, dlogits = loss_and_grad(self.criterion, output, labels)      # criterion(output, labels); loss.backward() (:81-83)
         output.backward(dlogits)
         self.optimizer.step()
+        return loss, output.detach()
+
+    def _device_state_fwd_bwd(self, rgb, mot, mr, mf, labels):
+        """The data-parallel step's first graph: tick + forward + loss + backward (the exchange and AdamW follow outside it)."""
+        from ..losses import loss_and_grad
+        self.optimizer.tick()
+        output = self.model(rgb, mot, mask_rgb=mr, mask_flow=mf)
+        loss, dlogits = loss_and_grad(self.criterion, output, labels)
+        output.backward(dlogits)
         return loss, output.detach()
 
     def train_epoch(self, epoch):
