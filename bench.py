@@ -681,6 +681,20 @@ def main():
             except Exception:
                 pass
             result["secondary_rooflines"] = sec
+            try:    # the clock THIS box holds under an MFMA load: kernels that are latency / issue bound (ViT attention: 160 us on one
+                    # box, 212 us on another in round 2) move with it, HBM-bound ones (add+LayerNorm) do not
+                from vimo_clip_amd._lib import check as _check, lib as _lib, ptr as _ptr, stream as _stream
+                stamps = torch.zeros(2 * 256, dtype=torch.int64, device=dev)
+                for _ in range(3):      # ~3 x 0.4 ms of back-to-back MFMAs; the last launch is read
+                    _check(_lib.vmc_clock_probe(_ptr(stamps), 256, 3000, _stream()), "clock_probe")
+                torch.cuda.synchronize()
+                st = stamps.view(256, 2).cpu().double()
+                mhz = (st[:, 0] / st[:, 1].clamp(min=1) * 100.0).sort().values
+                result["clock_probe"] = {"mfma_loop_mhz_median": round(float(mhz[128]), 1), "mhz_min": round(float(mhz[0]), 1),
+                                         "mhz_max": round(float(mhz[-1]), 1),
+                                         "note": "s_memtime / s_memrealtime around 192k bf16 MFMAs per wave, one workgroup per CU (vmc_clock_probe)"}
+            except Exception as e:      # noqa: BLE001
+                result["clock_probe"] = {"error": f"{type(e).__name__}: {e}"}
             big = [(s.elapsed_time(e) * 1e-3, f) for s, e, f, is_big in events if is_big]
             t_big = sum(t for t, _ in big)
             f_big = sum(f for _, f in big)

@@ -107,10 +107,20 @@ __device__ __forceinline__ void attn_chunk(const char* k_lds, const char* v_lds,
 // q / k / v are given as separate bases with their own row strides (the packed in_proj output is q = qkv, k = qkv + D, v = qkv + 2D,
 // all with stride 3D); NQ <= N query rows per frame are processed (NQ = 1: only the class token's query, the last block of the
 // encoder, whose other rows nothing reads).
-template <typename T, int NT, int NC>
-__global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
+// NW waves per workgroup.  NW = 4: one wave per SIMD per workgroup; hipcc hoists the loop-invariant K fragments (34 ds_read_b128 =
+// 136 VGPRs) out of the query-tile loop, which pins the kernel at 252 VGPRs = 2 waves per SIMD.  NW = 8 (REREAD): a compiler
+// barrier at the top of every query tile makes the K fragments be re-read from LDS per tile (they are there anyway), the body
+// fits 128 VGPRs and two co-resident workgroups put FOUR waves on every SIMD: the LDS / MFMA latencies one wave exposes are
+// covered by the other three (the loop was latency bound: ~30 s_waitcnt per tile at 2 waves per SIMD, 78 % issue utilisation).
+// PERSIST: the grid is 2 workgroups per CU and each walks (frame, head) pairs bh = blockIdx.x, + gridDim.x, ...: no workgroup
+// turnover between heads (PMC: wave lifetime x 8 rounds = 125 us of a 172 us launch).  stagger > 0: workgroups of the second
+// half of the grid (the second resident workgroup of each CU under round-robin dispatch -- speed only, never correctness) sleep
+// stagger x 8k cycles before their first head, so that one workgroup's K / V staging (HBM bound) runs under its neighbour's MFMAs.
+template <typename T, int NT, int NC, int NW = 4, bool REREAD = false, bool PERSIST = false>
+__global__ void __launch_bounds__(64 * NW, NW / 2) attn_vit_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                        const uint16_t* __restrict__ vp, uint16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int NQ, int H, size_t ldq, size_t ldkv, float scale) {
+                                                       float* __restrict__ lse, int N, int NQ, int H, size_t ldq, size_t ldkv, float scale,
+                                                       int n_bh = 0, int stagger = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKEYS = 16 * NT;
   char* const k_lds = smem;
@@ -118,7 +128,13 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int f = blockIdx.x / H, h = blockIdx.x % H;
+  if constexpr (PERSIST) {
+    if (stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  for (int bh = blockIdx.x; bh < (PERSIST ? n_bh : (int)blockIdx.x + 1); bh += PERSIST ? (int)gridDim.x : 1) {
+  if (PERSIST && bh != (int)blockIdx.x) __syncthreads();      // every wave is done with the previous head's K / V images
+  const int f = bh / H, h = bh % H;
   const int D = H * 64;
   const uint16_t* qbase = qp + (size_t)f * NQ * ldq + h * 64;
   const uint16_t* kbase = kp + (size_t)f * N * ldkv + h * 64;
@@ -128,11 +144,12 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   // all loads first (NKEYS*8/256 <= 9 chunks of K and of V per thread, registers are free before the compute
   // phase), then all LDS writes: one exposed HBM/L2 latency per block instead of one per chunk
   {
-    constexpr int ITERS = NKEYS * 8 / 256 > 0 ? NKEYS * 8 / 256 : 1;
+    constexpr int NTH = 64 * NW;
+    constexpr int ITERS = (NKEYS * 8 + NTH - 1) / NTH;
     uint4 kreg[ITERS], vreg[ITERS];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-      const int idx = i * 256 + tid;
+      const int idx = i * NTH + tid;
       const int row = idx >> 3, c = idx & 7;
       kreg[i] = vreg[i] = make_uint4(0, 0, 0, 0);
       if (idx < NKEYS * 8 && row < N) {
@@ -142,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
     }
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
-      const int idx = i * 256 + tid;
+      const int idx = i * NTH + tid;
       const int row = idx >> 3, c = idx & 7;
       if (idx < NKEYS * 8) {
         *(uint4*)(k_lds + lds_off_x(row, c)) = kreg[i];
@@ -162,15 +179,16 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
   uint4 qnext[2];
   // nqt = 17 for N = 257: one wave owns five query tiles, the others four.  Waves w of co-resident workgroups share a
   // SIMD, so the long wave rotates with the block index instead of always landing on SIMD 0.
-  const int w0 = (wave + blockIdx.x) & 3;
+  const int w0 = (wave + bh) & (NW - 1);
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(qbase + (size_t)min(w0 * 16 + r, NQ - 1) * ldq + (4 * kk + q) * 8);
-  for (int qt = w0; qt < nqt; qt += 4) {
+  for (int qt = w0; qt < nqt; qt += NW) {
+    if constexpr (REREAD) asm volatile("" ::: "memory");      // K fragments are re-read per tile, not kept in 136 registers
     const int qrow = qt * 16 + r;
     uint4 qf[2] = {qnext[0], qnext[1]};
-    if (qt + 4 < nqt) {  // prefetch the next query tile's fragments under this tile's MFMAs
+    if (qt + NW < nqt) {  // prefetch the next query tile's fragments under this tile's MFMAs
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(qbase + (size_t)min(qrow + 64, NQ - 1) * ldq + (4 * kk + q) * 8);
+      for (int kk = 0; kk < 2; ++kk) qnext[kk] = *(const uint4*)(qbase + (size_t)min(qrow + 16 * NW, NQ - 1) * ldq + (4 * kk + q) * 8);
     }
 
     // Keys are processed in one or two chunks (online softmax across chunks): two chunks keep the live score
@@ -193,13 +211,14 @@ __global__ void __launch_bounds__(256, 2) attn_vit_kernel(const uint16_t* __rest
         *(uint2*)(orow + 16 * dt) = make_uint2(pack2<T>(o[dt][0] * inv, o[dt][1] * inv), pack2<T>(o[dt][2] * inv, o[dt][3] * inv));
     }
   }
+  }      // (frame, head) walk
 }
 
 struct VitOperands { const uint16_t *q, *k, *v; size_t ldq, ldkv; int NQ; };
 
-template <typename T, int NT, int NC = 0>
-static int launch_vit(const VitOperands& a, void* out, float* lse, int F, int N, int H, hipStream_t stream) {
-  auto kern = attn_vit_kernel<T, NT, NC>;
+template <typename T, int NT, int NC = 0, int NW = 4, bool REREAD = false, bool PERSIST = false>
+static int launch_vit(const VitOperands& a, void* out, float* lse, int F, int N, int H, hipStream_t stream, int stagger = 0) {
+  auto kern = attn_vit_kernel<T, NT, NC, NW, REREAD, PERSIST>;
   constexpr int LDS = 16 * NT * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -207,13 +226,25 @@ static int launch_vit(const VitOperands& a, void* out, float* lse, int F, int N,
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(F * H), dim3(256), LDS, stream, a.q, a.k, a.v, (uint16_t*)out, lse, N, a.NQ, H, a.ldq, a.ldkv, 0.125f);
+  const int grid = PERSIST ? (F * H < 512 ? F * H : 512) : F * H;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDS, stream, a.q, a.k, a.v, (uint16_t*)out, lse, N, a.NQ, H, a.ldq, a.ldkv, 0.125f, F * H,
+                     stagger);
   VMC_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T>
 static int dispatch_vit(const VitOperands& qkv, void* out, float* lse, int F, int N, int H, hipStream_t s) {
+  if (N == 257 && qkv.NQ == N) {                                             // ViT-L/14 @ 224
+    // default: 8 waves, K fragments re-read per tile (112 VGPRs, 4 waves per SIMD): 167-169 us against 171-174 us per ViT-L/14 layer.
+    // VMC_ATTN_VARIANT (builder A/B switch): 9 = the 4-wave kernel of round 2 (252 VGPRs), 2 = 4 waves + re-read, 10+s / 20+s =
+    // persistent walks with a stagger of s sleeps (measured slower or equal: profiles/README.md)
+    static const int variant = getenv("VMC_ATTN_VARIANT") ? atoi(getenv("VMC_ATTN_VARIANT")) : 1;
+    if (variant == 1) return launch_vit<T, 18, 257, 8, true>(qkv, out, lse, F, N, H, s);
+    if (variant == 2) return launch_vit<T, 18, 257, 4, true>(qkv, out, lse, F, N, H, s);
+    if (variant >= 10 && variant < 20) return launch_vit<T, 18, 257, 4, false, true>(qkv, out, lse, F, N, H, s, variant - 10);
+    if (variant >= 20 && variant < 30) return launch_vit<T, 18, 257, 8, true, true>(qkv, out, lse, F, N, H, s, variant - 20);
+  }
   if (N == 257) return launch_vit<T, 18, 257>(qkv, out, lse, F, N, H, s);   // ViT-L/14 @ 224
   if (N == 197) return launch_vit<T, 14, 197>(qkv, out, lse, F, N, H, s);   // ViT-B/16
   if (N == 50) return launch_vit<T, 4, 50>(qkv, out, lse, F, N, H, s);      // ViT-B/32

@@ -164,3 +164,42 @@ extern "C" int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, co
   VMC_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---- sustained shader clock under an MFMA load (diagnostics: bench.py `clock_probe`) -----------------------------------------
+// One 256-thread workgroup per CU runs `iters` rounds of 64 dependent-free bf16 MFMAs on pseudo-random operands and stamps
+// s_memtime (shader cycles) and s_memrealtime (100 MHz) around them: cycles / ticks x 100 MHz = the clock the chip holds under
+// that load (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to `out` only; nothing else reads them.
+__global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long* __restrict__ out, int iters) {
+  const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+  uint4 a, b;
+  a.x = 0x3F803F80u ^ (seed & 0x007F007Fu); a.y = 0x3F003F80u ^ ((seed >> 3) & 0x007F007Fu);
+  a.z = 0xBF803F00u ^ ((seed >> 5) & 0x007F007Fu); a.w = 0x3F80BF80u ^ ((seed >> 7) & 0x007F007Fu);
+  b.x = a.y ^ 0x00110011u; b.y = a.z ^ 0x00220022u; b.z = a.w ^ 0x00330033u; b.w = a.x ^ 0x00440044u;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = BF16::mfma16(a, b, acc[i]);
+    a.x ^= (unsigned)it;
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sink = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (sink == 12345.678f) out[0] = 0;      // keeps the MFMAs alive
+}
+extern "C" int vmc_clock_probe(void* out, int workgroups, int iters, void* stream) {
+  if (!out || workgroups <= 0 || iters <= 0) return VMC_E_ARG;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
