@@ -686,7 +686,7 @@ def main():
                 from vimo_clip_amd._lib import check as _check, lib as _lib, ptr as _ptr, stream as _stream
                 stamps = torch.zeros(2 * 256, dtype=torch.int64, device=dev)
                 for _ in range(3):      # ~3 x 0.4 ms of back-to-back MFMAs; the last launch is read
-                    _check(_lib.vmc_clock_probe(_ptr(stamps), 256, 3000, _stream()), "clock_probe")
+                    _check(_lib.vmc_clock_probe(_ptr(stamps), 256, 3000, 0, _stream()), "clock_probe")
                 torch.cuda.synchronize()
                 st = stamps.view(256, 2).cpu().double()
                 mhz = (st[:, 0] / st[:, 1].clamp(min=1) * 100.0).sort().values

@@ -43,7 +43,7 @@ const char* vmc_error_string(int code);
 /* Diagnostics: `workgroups` workgroups of 256 threads run iters x 64 bf16 MFMAs and write {shader cycles (s_memtime), 100 MHz
  * ticks (s_memrealtime)} as two u64 each into out[2 * workgroups]: cycles / ticks x 100 MHz = the clock the chip sustains under an
  * MFMA load on THIS box (bench.py prints it beside the rooflines so that box-to-box swings of clock-sensitive kernels are visible). */
-int vmc_clock_probe(void* out, int workgroups, int iters, void* stream);
+int vmc_clock_probe(void* out, int workgroups, int iters, int mfma_shape /* 0: 16x16x32, 1: 32x32x16 (same FLOPs per round) */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K0 — frame preprocess + patch extraction.

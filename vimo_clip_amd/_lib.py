@@ -23,7 +23,7 @@ P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 SIGNATURES = {
     "vmc_abi_version": (I, []),
     "vmc_error_string": (c_char_p, [I]),
-    "vmc_clock_probe": (I, [P, I, I, P]),
+    "vmc_clock_probe": (I, [P, I, I, I, P]),
     "vmc_preprocess_patches_u8": (I, [P, P, I, I, I, I, I, I, P]),
     "vmc_patches_f32": (I, [P, P, I, I, I, I, I, P]),
     "vmc_patches_u8_exact": (I, [P, P, I, I, I, I, I, I, P]),

@@ -186,7 +186,7 @@ VMC_HD int g8_epi_kind(const GemmArgs& g) {
 // panels x 4 column panels: the 4 W panels (2 MB at K = 1024) stay resident in that XCD's 4 MB L2 for the whole sweep and
 // only A panels stream.  Widths 2 / 8 / 16 measured within 0.5 % (2-3 % slower on qkv): profiles/README.md round 2.
 __device__ __forceinline__ void g8_tile_coords(const GemmArgs& g, int tile, int& tm, int& tn) {
-  constexpr int GC = 4;
+  const int GC = g.walk_gc > 0 ? g.walk_gc : 4;
   const int gsz = g.tiles_m * GC, nfull = g.tiles_n / GC;
   const int cg = tile / gsz;
   if (cg < nfull) {
@@ -652,6 +652,8 @@ static int g8_act(GemmArgs& g, int act, hipStream_t s) {
 
 int vmc_gemm8_launch(GemmArgs& g, int act, int dtype16, hipStream_t stream) {
   if ((g.K & 127) != 0) return VMC_E_SHAPE;  // K tiles are consumed in pairs
+  static const int walk_gc = getenv("VMC_GEMM_GC") ? atoi(getenv("VMC_GEMM_GC")) : 0;      // builder A/B switch (profiles/README.md)
+  g.walk_gc = walk_gc;
   if (dtype16 == VMC_BF16) return g8_act<BF16>(g, act, stream);
   if (dtype16 == VMC_F16) return g8_act<F16>(g, act, stream);
   return VMC_E_DTYPE;

@@ -17,6 +17,7 @@ struct GemmArgs {
   char* zout;     // optional 16-bit side output [M, ldz]: the value before the activation (bias included) -- what the backward of
   int ldz;        // act(x W^T + b) needs, written by the same epilogue instead of a second pass (vmc_linear_preact)
   int variant;    // VMC_GEMM_* of include/vmc.h (per call; the library keeps no state)
+  int walk_gc;    // gemm8: column panels per tile-walk group (0 = 4, the default; VMC_GEMM_GC is the builder's A/B switch)
   int k_slices;   // > 1: split-K (gemm_kernel only): blockIdx.y owns a K range and atomically adds into the f32 output
 };
 

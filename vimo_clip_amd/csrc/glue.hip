@@ -170,6 +170,40 @@ extern "C" int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, co
 // One 256-thread workgroup per CU runs `iters` rounds of 64 dependent-free bf16 MFMAs on pseudo-random operands and stamps
 // s_memtime (shader cycles) and s_memrealtime (100 MHz) around them: cycles / ticks x 100 MHz = the clock the chip holds under
 // that load (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to `out` only; nothing else reads them.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// mode 0: v_mfma_f32_16x16x32_bf16, mode 1: v_mfma_f32_32x32x16_bf16 (same FLOPs per cycle; which clock does the chip hold?)
+__global__ void __launch_bounds__(256) clock_probe32_kernel(unsigned long long* __restrict__ out, int iters) {
+  const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+  uint4 a, b;
+  a.x = 0x3F803F80u ^ (seed & 0x007F007Fu); a.y = 0x3F003F80u ^ ((seed >> 3) & 0x007F007Fu);
+  a.z = 0xBF803F00u ^ ((seed >> 5) & 0x007F007Fu); a.w = 0x3F80BF80u ^ ((seed >> 7) & 0x007F007Fu);
+  b.x = a.y ^ 0x00110011u; b.y = a.z ^ 0x00220022u; b.z = a.w ^ 0x00330033u; b.w = a.x ^ 0x00440044u;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+    a.x ^= (unsigned)it;
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sink = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sink += acc[i][e];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (sink == 12345.678f) out[0] = 0;
+}
 __global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long* __restrict__ out, int iters) {
   const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
   uint4 a, b;
@@ -197,9 +231,12 @@ __global__ void __launch_bounds__(256) clock_probe_kernel(unsigned long long* __
   }
   if (sink == 12345.678f) out[0] = 0;      // keeps the MFMAs alive
 }
-extern "C" int vmc_clock_probe(void* out, int workgroups, int iters, void* stream) {
-  if (!out || workgroups <= 0 || iters <= 0) return VMC_E_ARG;
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
+extern "C" int vmc_clock_probe(void* out, int workgroups, int iters, int mfma_shape, void* stream) {
+  if (!out || workgroups <= 0 || iters <= 0 || mfma_shape < 0 || mfma_shape > 1) return VMC_E_ARG;
+  if (mfma_shape == 1)      // 32 MFMAs of 32x32x16 per round = the FLOPs of 64 MFMAs of 16x16x32
+    hipLaunchKernelGGL(clock_probe32_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
+  else
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
   VMC_CHECK_LAUNCH();
   return 0;
 }
