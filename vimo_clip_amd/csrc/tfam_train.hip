@@ -160,6 +160,10 @@ inline TrLayerWs tr_lw(const TrWs& w, const TrDims& d, int layer) { return tr_la
 // heavy: a LayerNorm (backward) prologue re-reads 32 fp32 rows (and more) per workgroup -- one workgroup per CU, wider tiles
 inline int tr_pick_bn(int M, int N, int rpb, int K, bool attn, bool heavy = false) {
   if (attn) return 16;
+  static const int force_ff = getenv("VMC_TR_BN_FF") ? atoi(getenv("VMC_TR_BN_FF")) : 0;      // builder A/B switch
+  static const int force_d = getenv("VMC_TR_BN_D") ? atoi(getenv("VMC_TR_BN_D")) : 0;
+  if (heavy && force_ff && N >= 1024 && N % force_ff == 0) return force_ff;
+  if (heavy && force_d && N < 1024 && N % force_d == 0) return force_d;
   const int n_rb = (M + rpb - 1) / rpb;
   const int cands[3] = {16, 32, 64};
   int best = 16;
@@ -578,9 +582,10 @@ struct TrLnProb {
   float* g_gamma;
   float* g_beta;
 };
+constexpr int TR_MAX_PROB = 32, TR_MAX_LN = 12;      // up to four layers' problems in one launch (deferred weight gradients)
 struct TrWgradGroup {
-  TrTnProb p[8];
-  TrLnProb ln[3];
+  TrTnProb p[TR_MAX_PROB];
+  TrLnProb ln[TR_MAX_LN];
   int nprob, total_tiles, nln, M, D;
 };
 
@@ -593,9 +598,8 @@ __global__ void __launch_bounds__(512) tr_wgrad_group_kernel(const TrWgradGroup 
   const int bid = (int)blockIdx.x - n_ln;
   if (bid >= 0) {
     int i = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-      if (k < g.nprob && bid >= g.p[k].tile0) i = k;
+    for (int k = 1; k < g.nprob; ++k)
+      if (bid >= g.p[k].tile0) i = k;
     const TrTnProb pr = g.p[i];
     const int local = bid - pr.tile0;
     tn_tile_body<T>(pr.dY, pr.X, pr.C, pr.dbias, pr.M, pr.N, pr.K, pr.lddy, pr.ldx, local / pr.tiles_k, local % pr.tiles_k, 0, (pr.M + 63) / 64, 0,
@@ -630,6 +634,7 @@ __global__ void __launch_bounds__(512) tr_wgrad_group_kernel(const TrWgradGroup 
 
 inline void tr_add_prob(TrWgradGroup& g, const uint16_t* dY, const uint16_t* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx) {
   if (C == nullptr && dbias == nullptr) return;
+  if (g.nprob >= TR_MAX_PROB) { g.nprob = TR_MAX_PROB + 1; return; }      // overflow: reported by tr_wgrad_launch
   TrTnProb& p = g.p[g.nprob++];
   p.dY = dY; p.X = X; p.C = C; p.dbias = dbias; p.M = M; p.N = N; p.K = K; p.lddy = lddy; p.ldx = ldx;
   p.tiles_k = (K + 127) / 128;
@@ -638,11 +643,13 @@ inline void tr_add_prob(TrWgradGroup& g, const uint16_t* dY, const uint16_t* X, 
 }
 inline void tr_add_ln(TrWgradGroup& g, const float* dx, const float* y, const float* stats, float* gg, float* gb) {
   if (gg == nullptr && gb == nullptr) return;
+  if (g.nln >= TR_MAX_LN) { g.nln = TR_MAX_LN + 1; return; }
   TrLnProb& l = g.ln[g.nln++];
   l.dx = dx; l.y = y; l.stats = stats; l.g_gamma = gg; l.g_beta = gb;
 }
 template <typename T>
 int tr_wgrad_launch(const TrWgradGroup& g, hipStream_t s) {
+  if (g.nprob > TR_MAX_PROB || g.nln > TR_MAX_LN) return VMC_E_SHAPE;
   const int blocks = g.total_tiles + g.nln * (g.D / 64);
   if (blocks == 0) return 0;
   for (int i = 0; i < g.nprob; ++i)
@@ -657,9 +664,11 @@ int tr_wgrad_launch(const TrWgradGroup& g, hipStream_t s) {
 }
 
 // ---- backward of one layer -------------------------------------------------------------------------------------------------
+// defer != null: the layer's weight-gradient problems are appended to *defer instead of being launched (vmc_tfam_train_bwd launches
+// all layers' problems once, after the last dgrad chain: one HBM-write-bound launch instead of four with a tail each)
 template <typename T>
 int tr_layer_bwd(const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_layer_params* layers, int layer, const TrDims& d, const TrWs& ws,
-                 float p, const uint64_t* seeds, int dtype16, hipStream_t s) {
+                 float p, const uint64_t* seeds, int dtype16, hipStream_t s, TrWgradGroup* defer = nullptr) {
   const int M = d.B * d.T, Mk = d.B * d.Tk, D = d.D, dh = D / d.H;
   const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
   const vmc_tfam_layer_params& P = layers[layer];
@@ -737,7 +746,8 @@ int tr_layer_bwd(const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_lay
     if ((rc = tr_ring<T>(a, s))) return rc;
   }
   // weight, bias and LayerNorm-parameter gradients: one grouped launch
-  TrWgradGroup g = {};
+  TrWgradGroup local = {};
+  TrWgradGroup& g = defer ? *defer : local;
   g.M = M; g.D = D;
   tr_add_prob(g, w.dqkv16, w.x0_16, P.gw_self_in, P.gb_self_in, M, 3 * D, D, 3 * D, D);
   tr_add_prob(g, w.d1_16, w.o_self, P.gw_self_out, P.gb_self_out, M, D, D, D, D);
@@ -752,7 +762,7 @@ int tr_layer_bwd(const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_lay
   tr_add_ln(g, w.dx3, w.y3, w.st3, P.g_ln_ffn_g, P.g_ln_ffn_b);
   if (d.has_cross) tr_add_ln(g, w.dx2, w.y2, w.st2, P.g_ln_cross_g, P.g_ln_cross_b);
   tr_add_ln(g, dx_self, w.y1, w.st1, P.g_ln_self_g, P.g_ln_self_b);
-  return tr_wgrad_launch<T>(g, s);
+  return defer ? 0 : tr_wgrad_launch<T>(g, s);
 }
 
 inline bool tr_ws_ok(const void* ws, size_t bytes, const TrWs& w) { return ws != nullptr && bytes >= w.bytes && (((uintptr_t)ws) & 255) == 0; }
@@ -830,8 +840,23 @@ extern "C" int vmc_tfam_train_bwd(const float* dlogits, const uint8_t* mask, con
   if (p_mlp > 0.f && !seeds) return VMC_E_ARG;
   int rc = vmc_tfam_head_bwd(dlogits, layers, head, workspace, workspace_bytes, B, T, Tk, D, H, ff, L, C, has_cross, p_mlp, seeds ? seeds[7 * L] : 0, dtype16,
                              stream);
-  for (int l = L - 1; l >= 0 && rc == 0; --l)
-    rc = vmc_tfam_layer_bwd(mask, mask_kv, layers, l, workspace, workspace_bytes, B, T, Tk, D, H, ff, L, C, has_cross, p_drop,
-                            seeds ? seeds + 7 * l : nullptr, dtype16, stream);
-  return rc;
+  if (rc) return rc;
+  TR_PROLOG();
+  if (!layers || (p_drop > 0.f && !seeds)) return VMC_E_ARG;
+  // the dgrad chains of all layers first, then every weight gradient in ONE launch (the per-layer entry point launches its own).
+  // Four layers' problems fit the table; deeper models flush it every four layers.
+  TrWgradGroup g = {};
+  int pending = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    rc = dtype16 == VMC_BF16 ? tr_layer_bwd<BF16>(mask, mask_kv, layers, l, d, ws, p_drop, seeds ? seeds + 7 * l : nullptr, dtype16, s, &g)
+                             : tr_layer_bwd<F16>(mask, mask_kv, layers, l, d, ws, p_drop, seeds ? seeds + 7 * l : nullptr, dtype16, s, &g);
+    if (rc) return rc;
+    if (++pending == 4 || l == 0) {
+      rc = dtype16 == VMC_BF16 ? tr_wgrad_launch<BF16>(g, s) : tr_wgrad_launch<F16>(g, s);
+      if (rc) return rc;
+      g = TrWgradGroup{};
+      pending = 0;
+    }
+  }
+  return 0;
 }

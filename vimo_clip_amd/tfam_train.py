@@ -216,26 +216,33 @@ class TfamTrainFn(torch.autograd.Function):
         sarr, nbytes = ctx.sarr, ws.numel()
         off = ctypes.sizeof(ctypes.c_uint64)
         seed_at = (lambda i: ctypes.cast(ctypes.addressof(sarr) + i * off, ctypes.c_void_p)) if sarr is not None else (lambda i: None)
-        check(lib.vmc_tfam_head_bwd(ptr(dlogits), layers, ctypes.byref(head), ptr(ws), nbytes, *dims, p_mlp,
-                                    int(sarr[SEEDS_PER_LAYER * L]) if sarr is not None else 0, dt(dt16), stream()), "tfam_head_bwd")
-        c = model.classifier
-        _report((c[4].weight, c[4].bias, c[1].weight, c[1].bias, c[0].weight, c[0].bias))
         done = getattr(model, "grad_group_callback", None)      # e.g. FusedAdam.group_ready: the optimiser step of a finished group
-        if done is not None:                                     # runs beside the rest of the backward (group L = the classifier)
-            done(L)
-        for l in range(L - 1, -1, -1):
-            check(lib.vmc_tfam_layer_bwd(ptr(mask), ptr(mask_kv) if cross else None, layers, l, ptr(ws), nbytes, *dims, p_drop,
-                                         seed_at(SEEDS_PER_LAYER * l), dt(dt16), stream()), "tfam_layer_bwd")
-            layer = model.layers[l]
-            sa, ca = layer.self_attn, layer.cross_attn
-            rep = [layer.norm_ffn.weight, layer.norm_ffn.bias, layer.ffn[3].weight, layer.ffn[3].bias, layer.ffn[0].weight, layer.ffn[0].bias]
-            if cross:      # the per-op path reports the packed cross in_proj twice (q rows, k|v rows): same counts here (parallel.GradientAllReducer)
-                rep += [layer.norm_cross.weight, layer.norm_cross.bias, ca.out_proj.weight, ca.out_proj.bias, ca.in_proj_weight, ca.in_proj_bias,
-                        ca.in_proj_weight, ca.in_proj_bias]
-            rep += [layer.norm_self.weight, layer.norm_self.bias, sa.out_proj.weight, sa.out_proj.bias, sa.in_proj_weight, sa.in_proj_bias]
-            _report(rep)
-            if done is not None:
-                done(l)
+        c = model.classifier
+        head_params = (c[4].weight, c[4].bias, c[1].weight, c[1].bias, c[0].weight, c[0].bias)
+        if not ag.grad_ready_hooks and done is None:
+            # nobody waits for a layer's gradients (single process): the whole backward in one call -- the dgrad chains of all layers,
+            # then every weight gradient in ONE grouped launch (vmc_tfam_train_bwd)
+            check(lib.vmc_tfam_train_bwd(ptr(dlogits), ptr(mask), ptr(mask_kv) if cross else None, layers, ctypes.byref(head), ptr(ws), nbytes,
+                                         *dims, p_drop, p_mlp, sarr, dt(dt16), stream()), "tfam_train_bwd")
+        else:
+            check(lib.vmc_tfam_head_bwd(ptr(dlogits), layers, ctypes.byref(head), ptr(ws), nbytes, *dims, p_mlp,
+                                        int(sarr[SEEDS_PER_LAYER * L]) if sarr is not None else 0, dt(dt16), stream()), "tfam_head_bwd")
+            _report(head_params)
+            if done is not None:                                 # group L = the classifier
+                done(L)
+            for l in range(L - 1, -1, -1):
+                check(lib.vmc_tfam_layer_bwd(ptr(mask), ptr(mask_kv) if cross else None, layers, l, ptr(ws), nbytes, *dims, p_drop,
+                                             seed_at(SEEDS_PER_LAYER * l), dt(dt16), stream()), "tfam_layer_bwd")
+                layer = model.layers[l]
+                sa, ca = layer.self_attn, layer.cross_attn
+                rep = [layer.norm_ffn.weight, layer.norm_ffn.bias, layer.ffn[3].weight, layer.ffn[3].bias, layer.ffn[0].weight, layer.ffn[0].bias]
+                if cross:      # the per-op path reports the packed cross in_proj twice (q rows, k|v rows): same counts here (parallel.GradientAllReducer)
+                    rep += [layer.norm_cross.weight, layer.norm_cross.bias, ca.out_proj.weight, ca.out_proj.bias, ca.in_proj_weight, ca.in_proj_bias,
+                            ca.in_proj_weight, ca.in_proj_bias]
+                rep += [layer.norm_self.weight, layer.norm_self.bias, sa.out_proj.weight, sa.out_proj.bias, sa.in_proj_weight, sa.in_proj_bias]
+                _report(rep)
+                if done is not None:
+                    done(l)
         grads = tuple((fresh.get(id(p)) if p.requires_grad and getattr(p, "_vmc_grad", None) is None else None) for p in ctx.params)
         ctx.ws = None
         return (None,) * 9 + grads
