@@ -16,7 +16,7 @@ from vimo_clip_amd import synth
 
 pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
-FUSED_CASES = [c for c in mg.TFAM_CASES if c["name"] != "cross_long"]      # T = 40 > 32: outside the chain, per-op path
+FUSED_CASES = list(mg.TFAM_CASES)      # incl. cross_long (T = 40, Tk = 39): clips of up to 64 tokens run through the chain (round 3)
 
 
 def _tfam(c, dtype):
@@ -125,6 +125,30 @@ def test_fused_chain_vs_oracle_over_batch_sizes(B, dtype):
     assert err <= TOL[dtype] * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("D,H,Tr,Tf,ragged", [(512, 8, 40, 39, True), (768, 8, 64, 63, True), (768, 8, 33, 20, False), (768, 12, 48, 64, True),
+                                              (512, 8, 20, 50, True)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_clips_longer_than_32_tokens_run_through_the_chain(D, H, Tr, Tf, ragged, dtype, monkeypatch):
+    """real Animal-Kingdom clips are longer than 32 tokens (the reference consumes whole videos).  Queries in parts of 32
+    per row block, up to four key tiles of 16 (the V image shares its LDS region with the W tile), fragment records of ceil(T / 16)
+    token tiles: T and Tk up to 64 against the CPU oracle, ragged masks, d_model 512 and 768, head_dim 64 and 96."""
+    from vimo_clip_amd import tfam_fused as tf
+    c = dict(name="long", D=D, H=H, L=2, ff=1024, C=140, B=3, Tr=Tr, Tf=Tf, mode="cross", pe=False, ragged=ragged, seed=970 + Tr)
+    m = _tfam(c, dtype)
+    calls = []
+    orig = tf.TfamPack.forward
+    monkeypatch.setattr(tf.TfamPack, "forward", lambda self, *a, **k: calls.append(1) or orig(self, *a, **k))
+    rgb, mot, mr, mf = mg.tfam_inputs(c)
+    with torch.no_grad():
+        y = m(rgb.cuda(), mot.cuda(), mask_rgb=mr.cuda(), mask_flow=mf.cuda()).cpu()
+    assert calls, "the fused chain was not used"
+    sd = synth.tfam_state_dict(c["D"], c["H"], c["L"], c["ff"], c["C"], c["seed"])
+    ref = otfam.amo_clip_forward(sd, rgb, mot, mr, mf, nhead=H)
+    err = (y - ref).abs().max().item()
+    print(f"fused T={Tr} Tk={Tf} D={D} H={H} {dtype}: max abs err {err:.3e} (|ref|max {ref.abs().max():.2f})")
+    assert err <= TOL[dtype] * max(1.0, ref.abs().max().item())
+
+
 def test_long_clips_T32_and_no_masks():
     c = dict(name="t32", D=512, H=8, L=2, ff=2048, C=140, B=3, Tr=32, Tf=31, mode="cross", pe=False, ragged=False, seed=950)
     m = _tfam(c, torch.float16)
@@ -163,7 +187,7 @@ def test_layerwise_entry_points_equal_the_single_call():
     # argument checking: unsupported shapes are refused, not mis-executed
     assert lib.vmc_tfam_layer_fwd(None, None, None, ptr(pack.wpack), ptr(pack.ppack), 0, ptr(ws), ws.numel(), *dims, 1, 1, stream()) == -1
     assert lib.vmc_tfam_kv_fwd(ptr(mo), ptr(pack.wpack), ptr(pack.ppack), ptr(ws), 16, *dims, 1, stream()) == -1
-    bad = (B, 40, Tk, D, pack.H, pack.ff, pack.L, pack.C)
+    bad = (B, 70, Tk, D, pack.H, pack.ff, pack.L, pack.C)      # more than TF_MAX_T = 64 tokens per clip
     assert lib.vmc_tfam_head_fwd(ptr(pack.wpack), ptr(pack.ppack), ptr(out), ptr(ws), ws.numel(), *bad, 1, 1, stream()) == -3
 
 

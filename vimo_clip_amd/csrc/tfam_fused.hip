@@ -98,7 +98,7 @@ inline TfWs tf_ws(void* base, const TfDims& d) {
   w.pool = (uint16_t*)(p + o); o += al((size_t)d.B * d.D * 2);
   w.g = (uint16_t*)(p + o); o += al((size_t)d.B * (d.D / 2) * 2);
   const int H = d.H > 0 ? d.H : 8, dh = d.D / H;
-  const size_t fe = tf_frag_elems(d.B, H, dh);
+  const size_t fe = tf_frag_elems(d.B, H, dh, tf_ntt(d.T > d.Tk ? d.T : d.Tk));
   w.qf = (uint16_t*)(p + o); o += al(fe * 2);
   w.kf = (uint16_t*)(p + o); o += al(fe * 2);
   w.kxf = (uint16_t*)(p + o); w.kxf_stride = al(fe * 2) / 2; o += (d.has_cross ? d.L : 0) * al(fe * 2);
@@ -146,7 +146,7 @@ inline TfArgs tf_kv_layer_args(const float* motion, const uint16_t* wp, const fl
   a.bias = pp + vmc_tfam_pack_offset(VMC_TFAM_P_KV_ALL_B, layer, d.D, d.ff, d.L, d.C);
   a.out = w.kv + (size_t)layer * 2 * d.D; a.ldo = d.L * 2 * d.D; a.act = VMC_ACT_NONE;
   a.frag[0] = w.kxf + (size_t)layer * w.kxf_stride; a.frag[1] = nullptr;      // K columns fragment-major, V columns row-major
-  a.frag_D = d.D; a.frag_T = d.Tk; a.frag_H = d.H; a.frag_DH = d.D / d.H;
+  a.frag_D = d.D; a.frag_T = d.Tk; a.frag_H = d.H; a.frag_DH = d.D / d.H; a.frag_NTT = tf_ntt(d.Tk);
   return a;
 }
 
@@ -169,7 +169,9 @@ template <typename T>
 int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv, const uint16_t* wp, const float* pp, int layer,
                   const TfDims& d, const TfWs& w, hipStream_t s, const float* merge_kv_motion = nullptr) {
   const int M = d.B * d.T, D = d.D, dh = D / d.H;
-  const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
+  // row blocks: two whole clips (T <= 16), one clip (T <= 32), or -- longer clips -- uniform 32-row blocks for the row-wise GEMMs
+  // and (clip, 32-query part) blocks for the two attention launches
+  const int cpb = d.T <= 16 ? 2 : 1, parts = d.T > 32 ? (d.T + 31) / 32 : 1, rpb = d.T > 32 ? 32 : cpb * d.T;
   const float scale = 1.0f / sqrtf((float)dh);
   auto W = [&](int slot) { return wp + vmc_tfam_pack_offset(slot, layer, D, d.ff, d.L, d.C); };
   auto P = [&](int slot, int l) { return pp + vmc_tfam_pack_offset(slot, l, D, d.ff, d.L, d.C); };
@@ -181,6 +183,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     a.W = W(VMC_TFAM_W_SELF_IN); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_IN_B, layer);
     a.out = w.qkv; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
     a.frag[0] = w.qf; a.frag[1] = w.kf; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;    // V columns stay row-major
+    a.frag_NTT = tf_ntt(d.T);
     const bool pair = merge_kv_motion != nullptr && d.has_cross;
     TfArgs b = {};
     int bn = tf_pick_bn(M, a.N, rpb, D, false);
@@ -200,12 +203,14 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
     }
     if (rc) return rc;
   }
-  const int bn_attn = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.T + (d.T > 16 ? 32 : 16));
-  const int bn_cross = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.Tk + (d.Tk > 16 ? 32 : 16));
+  auto keyrows = [](int tk) { return tk > 32 ? 64 : (tk > 16 ? 32 : 16); };
+  const int bn_attn = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.T + keyrows(d.T));
+  const int bn_cross = tf_pick_bn(M, D, rpb, D, true, (cpb - 1) * d.Tk + keyrows(d.Tk));
   {  // 2: y = resid + selfattn(qkv) Wo^T + b
     TfArgs a = {};
     a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
     a.q = w.qf; a.k = w.kf; a.v = w.qkv + 2 * D; a.ldv = 3 * D;
+    a.parts = parts; a.ntt_q = a.ntt_k = tf_ntt(d.T);
     a.kmask = mask; a.T = d.T; a.Tk = d.T; a.H = d.H; a.B = d.B; a.scale = scale;
     a.W = W(VMC_TFAM_W_SELF_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_SELF_OUT_B, layer);
     a.resid = resid; a.ldres = D; a.out = w.y; a.ldo = D;
@@ -220,7 +225,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
       a.A = w.y; a.lda = D; a.eps = 1e-5f; a.ln_g = ln_g; a.ln_b = ln_g + D; a.xout = w.xb;
       a.W = W(VMC_TFAM_W_CROSS_Q); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_Q_B, layer);
       a.out = w.q; a.ldo = D; a.act = VMC_ACT_NONE;
-      a.frag[0] = w.qf; a.frag[1] = nullptr; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;
+      a.frag[0] = w.qf; a.frag[1] = nullptr; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh; a.frag_NTT = tf_ntt(d.T);
       if ((rc = tf_gemm_k<T, PRO_LN, EPI_ACT16>(a, tf_pick_bn(M, a.N, rpb, D, false), s))) return rc;
     }
     {  // 4: y = xb + crossattn(q, K_l, V_l) Wo^T + b
@@ -228,6 +233,7 @@ int tf_layer_impl(const float* x_in, const uint8_t* mask, const uint8_t* mask_kv
       a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
       a.q = w.qf;
       a.k = w.kxf + (size_t)layer * w.kxf_stride; a.v = w.kv + (size_t)layer * 2 * D + D; a.ldv = d.L * 2 * D;
+      a.parts = parts; a.ntt_q = tf_ntt(d.T); a.ntt_k = tf_ntt(d.Tk);
       a.kmask = mask_kv; a.T = d.T; a.Tk = d.Tk; a.H = d.H; a.B = d.B; a.scale = scale;
       a.W = W(VMC_TFAM_W_CROSS_OUT); a.ldw = D; a.bias = P(VMC_TFAM_P_CROSS_OUT_B, layer);
       a.resid = w.xb; a.ldres = D; a.out = w.y; a.ldo = D;

@@ -7,6 +7,7 @@ namespace {
 
 constexpr int TF_BM = 32;
 constexpr int TF_NTH = 256;
+constexpr int TF_MAX_T = 64;      // tokens per clip (queries in parts of 32 per row block, up to four key tiles)
 
 enum { PRO_F32 = 0, PRO_LN = 1, PRO_16 = 2, PRO_ATTN = 3, PRO_LNBWD = 4 };
 enum { EPI_ACT16 = 0, EPI_RESID32 = 1, EPI_BIAS32 = 2 };
@@ -37,6 +38,10 @@ struct TfArgs {
   int M, N, K;
   int rpb;                  // token rows per row block (<= 32)
   int n_tiles, n_rb;
+  int parts;                // PRO_ATTN launches of clips longer than 32 tokens: row block rb = (clip rb / parts, query rows 32 (rb % parts)..);
+                            // 0 / 1: uniform blocks of rpb rows (cpb whole clips)
+  int ntt_q, ntt_k;         // PRO_ATTN: token tiles per (clip, head) record of the q / k fragment buffers (tf_ntt)
+  int frag_NTT;             // EPI_ACT16 fragment outputs: token tiles per record (0 = 2)
   int act;
   // ---- training chain (TR instantiations only; tfam_train.hip) ----------------------------------------------------------
   int ln_affine;            // PRO_LN: gamma / beta applied in the prologue (unfolded weights)
@@ -61,15 +66,40 @@ struct TfArgs {
 
 __device__ __forceinline__ int swz16(int chunk, int row) { return chunk ^ (row & 15); }
 
+// First clip and first query token of row block rb, and the global row of its local row `lrow` (valid = a real row of the block).
+__device__ __forceinline__ void tf_block_origin(const TfArgs& a, int rb, int& clip0, int& tq0) {
+  if (a.parts > 1) {
+    clip0 = rb / a.parts;
+    tq0 = 32 * (rb - clip0 * a.parts);
+  } else {
+    clip0 = rb * a.cpb;
+    tq0 = 0;
+  }
+}
+__device__ __forceinline__ int tf_grow(const TfArgs& a, int rb, int lrow, bool& valid) {
+  if (a.parts > 1) {
+    const int clip = rb / a.parts, t = 32 * (rb - clip * a.parts) + lrow;
+    valid = lrow < 32 && t < a.T;
+    return clip * a.T + min(t, a.T - 1);
+  }
+  const int g = rb * a.rpb + lrow;
+  valid = lrow < a.rpb && g < a.M;
+  return min(g, a.M - 1);
+}
+
 // Fragment-major layout of a q / k matrix: the 16 B an MFMA lane needs (token r of a 16-token tile, head-dim chunk 4 kk + qq)
 // sit at lane (16 qq + r) x 16 B of a 1-KiB record per (clip, head, token tile, kk) -- one fully coalesced wave load per
 // fragment, where row-major [token][feature] rows give 16 rows x 64 B per instruction (measured: the fragment-shaped loads
 // of 2 (clip, head) pairs cost 3.7 us of a 9.9 us launch).  Element offset of (clip, head, token t, head-dim d):
-__host__ __device__ __forceinline__ size_t tf_frag_off(int clip, int head, int t, int d, int H, int DH) {
+// NTT = token tiles of 16 per (clip, head): tf_ntt(T) = max(2, ceil(T / 16)) (clips of up to 32 tokens keep the two-tile records).
+__host__ __device__ __forceinline__ int tf_ntt(int T) { return T <= 32 ? 2 : (T + 15) >> 4; }
+__host__ __device__ __forceinline__ size_t tf_frag_off(int clip, int head, int t, int d, int H, int DH, int NTT = 2) {
   const int KK = DH >> 5;
-  return ((((size_t)(clip * H + head) * 2 + (t >> 4)) * KK + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (t & 15)) * 8 + (d & 7);
+  return ((((size_t)(clip * H + head) * NTT + (t >> 4)) * KK + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + (t & 15)) * 8 + (d & 7);
 }
-__host__ __device__ __forceinline__ size_t tf_frag_elems(int clips, int H, int DH) { return (size_t)clips * H * 2 * (DH >> 5) * 512; }
+__host__ __device__ __forceinline__ size_t tf_frag_elems(int clips, int H, int DH, int NTT = 2) {
+  return (size_t)clips * H * NTT * (DH >> 5) * 512;
+}
 
 // (n tile, row block) of a block id: blocks that share a W tile agree mod 8 -> same XCD (round-robin dispatch).
 __device__ __forceinline__ void tf_block_map(int bid, int n_tiles, int n_rb, int& nt, int& rb) {
@@ -283,10 +313,9 @@ __device__ __forceinline__ void tf_pro_16(const TfArgs& a, char* a_img, int rb, 
 // V rows of the block's clips -> LDS image [vrows][D] by LDS-DMA: vrows = (cpb-1)*Tk + 16*NKT, NKT = key tiles (Tk <= 16: keys
 // 16..31 of the 32-key P V step are fed as zeros, no LDS rows); rows past the data repeat the last key (finite values under
 // a zero probability).
-__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int rb, int vrows, int wave, int lane, int nw) {
+__device__ __forceinline__ void tf_stage_v(const TfArgs& a, char* v_img, int c0, int vrows, int wave, int lane, int nw) {
   const int cpr = a.K >> 3;
   const int total = (vrows * cpr + 63) >> 6;
-  const int c0 = rb * a.cpb;
   for (int ii = wave; ii < total; ii += nw) {
     const int p = min(ii * 64 + lane, vrows * cpr - 1);
     const int row = p / cpr, phys = p - row * cpr;
@@ -313,48 +342,43 @@ struct TfAttnFrags {
 // liveness of this lane's keys: plain global loads, issued together with the LDS-DMA of the V and W images so that one round
 // trip covers all of them.  Token rows >= T (or Tk) of a tile were never written: they only reach masked scores / unused rows.
 template <int DH, int QT, int NKT, int NW>
-__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, int rb, int p0, int lane) {
+__device__ __forceinline__ void tf_attn_load(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, int c0, int tq0, int p0, int lane) {
   constexpr int KK = DH / 32, PB = (16 / NW) / QT;
-  const int c0 = rb * a.cpb, npairs = a.cpb * a.H;
+  const int npairs = a.cpb * a.H;
+  const int nq = a.ntt_q > 0 ? a.ntt_q : 2, nk = a.ntt_k > 0 ? a.ntt_k : 2, qt0 = tq0 >> 4;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int p = min(p0 + i, npairs - 1);
     const int ci = p / a.H, h = p - ci * a.H;
     const int clip = min(c0 + ci, a.B - 1);
-    const size_t rec = (size_t)(clip * a.H + h) * 2 * KK;       // 1-KiB records of this (clip, head): [token tile][kk]
+    const size_t krec = (size_t)(clip * a.H + h) * nk * KK;     // 1-KiB records of this (clip, head): [token tile][kk]
+    const size_t qrec = (size_t)(clip * a.H + h) * nq * KK;
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(a.k + (rec + nt * KK + kk) * 512 + lane * 8);
+      for (int kk = 0; kk < KK; ++kk) f.kf[i][nt][kk] = *(const uint4*)(a.k + (krec + min(nt, nk - 1) * KK + kk) * 512 + lane * 8);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(a.q + (rec + qt * KK + kk) * 512 + lane * 8);
+      for (int kk = 0; kk < KK; ++kk) f.qf[i][qt][kk] = *(const uint4*)(a.q + (qrec + min(qt0 + qt, nq - 1) * KK + kk) * 512 + lane * 8);
   }
 }
 
-__device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebits)[2], int rb, int lane) {
-  const int q = lane >> 4, c0 = rb * a.cpb;
+// livebits[ci] bit 4 nt + j: key 16 nt + 4 q + j of clip ci exists and is not masked (nt < 4)
+__device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebits)[2], int c0, int lane) {
+  const int q = lane >> 4;
   livebits[0] = livebits[1] = 0u;
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci) {
     const int clip = min(c0 + min(ci, a.cpb - 1), a.B - 1);
-    uint32_t lo = 0x01010101u, hi = 0x01010101u;                  // mask bytes of keys 4q..4q+3 and 16+4q..
-    if (a.kmask != nullptr) {
-      const uint8_t* mk = a.kmask + (size_t)clip * a.Tk;
+    const uint8_t* mk = a.kmask != nullptr ? a.kmask + (size_t)clip * a.Tk : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k0 = 4 * q + j, k1 = 16 + 4 * q + j;
-        const uint32_t m0 = mk[min(k0, a.Tk - 1)], m1 = mk[min(k1, a.Tk - 1)];
-        lo = (lo & ~(0xFFu << (8 * j))) | ((m0 ? 1u : 0u) << (8 * j));
-        hi = (hi & ~(0xFFu << (8 * j))) | ((m1 ? 1u : 0u) << (8 * j));
+        const int key = 16 * nt + 4 * q + j;
+        if (key < a.Tk && (mk == nullptr || mk[key] != 0)) livebits[ci] |= 1u << (4 * nt + j);
       }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (4 * q + j < a.Tk && ((lo >> (8 * j)) & 1u)) livebits[ci] |= 1u << j;
-      if (16 + 4 * q + j < a.Tk && ((hi >> (8 * j)) & 1u)) livebits[ci] |= 1u << (4 + j);
-    }
   }
 }
 
@@ -363,9 +387,9 @@ __device__ __forceinline__ void tf_attn_live(const TfArgs& a, uint32_t (&livebit
 // of O^T = V^T P^T, V^T fragments by ds_read_b64_tr_b16 from the LDS image.  O (normalised) is written as the 16-bit A
 // operand of the out_proj GEMM.
 template <typename T, int DH, int QT, int NKT, int NW, bool TR = false>
-__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, char* a_img, const char* v_img, int rb, int wave,
-                                            int lane, int nt_blk = 0) {
-  constexpr int KK = DH / 32, DT = DH / 16, PB = (16 / NW) / QT;
+__device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT, NKT, NW>& f, char* a_img, const char* v_img, int c0, int tq0,
+                                            int wave, int lane, int nt_blk = 0) {
+  constexpr int KK = DH / 32, DT = DH / 16, PB = (16 / NW) / QT, NKS = (NKT + 1) / 2;      // NKS: 32-key steps of P V
   const int r = lane & 15, q = lane >> 4;
   const int npairs = a.cpb * a.H;
   const int rowb = a.K * 2;
@@ -374,7 +398,7 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
   uint64_t seed = 0;
   if constexpr (TR) seed = a.p_attn > 0.f ? resolve_seed(a.seed_attn) : 0;
   for (int p0 = wave * PB; p0 < npairs; p0 += NW * PB) {
-    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT, NW>(a, f, rb, p0, lane);     // later batches (nhead > 8): a round trip of their own
+    if (p0 != wave * PB) tf_attn_load<DH, QT, NKT, NW>(a, f, c0, tq0, p0, lane);     // later batches (nhead > 8): a round trip of their own
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const bool valid = p0 + i < npairs;           // no early exit: the PB chains are independent and get interleaved
@@ -383,8 +407,8 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
       const uint32_t lb = ci ? f.livebits[1] : f.livebits[0];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        f32x4 s[2];
-        s[1] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // NKT == 1: keys 16..31 do not exist
+        const int tq = tq0 + 16 * qt + r;           // this lane's query token inside its clip
+        f32x4 s[NKT];
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt) {
           s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -402,61 +426,64 @@ __device__ __forceinline__ void tf_pro_attn(const TfArgs& a, TfAttnFrags<DH, QT,
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         const float mc = m * c2;                  // a fully masked row gives exp2(NaN): NaN output, as torch
-        float pe[8];
+        float pe[NKS][8];
+        uint4 pf[NKS];
+        f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pe[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][j], c2, -mc));
-          pe[4 + j] = NKT == 2 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][j], c2, -mc)) : 0.f;
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pe[ks][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * ks][j], c2, -mc));
+            pe[ks][4 + j] = 2 * ks + 1 < NKT ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * ks + 1 < NKT ? 2 * ks + 1 : 0][j], c2, -mc)) : 0.f;
+          }
+          pf[ks] = make_uint4(pack2<T>(pe[ks][0], pe[ks][1]), pack2<T>(pe[ks][2], pe[ks][3]), pack2<T>(pe[ks][4], pe[ks][5]),
+                              pack2<T>(pe[ks][6], pe[ks][7]));
+          osum = T::mfma16(ones, pf[ks], osum);
         }
-        uint4 pf;
-        pf.x = pack2<T>(pe[0], pe[1]);
-        pf.y = pack2<T>(pe[2], pe[3]);
-        pf.z = pf.w = 0u;
-        if constexpr (NKT == 2) {
-          pf.z = pack2<T>(pe[4], pe[5]);
-          pf.w = pack2<T>(pe[6], pe[7]);
-        }
-        f32x4 osum = T::mfma16(ones, pf, (f32x4){0.f, 0.f, 0.f, 0.f});
         if constexpr (TR) {
           // nn.MultiheadAttention(dropout=p): softmax normalised by the UNdropped sum, P V on p * keep / (1 - p) with the
           // counter-based mask of vmc_attention_fwd / _bwd (same flat (clip, head, query, key) index)
           if (a.p_attn > 0.f) {                   // wave-uniform
-            const int clip = min(rb * a.cpb + ci, a.B - 1);
-            const size_t base = (((size_t)clip * a.H + h) * a.T + min(16 * qt + r, a.T - 1)) * a.Tk + 4 * q;
+            const int clip = min(c0 + ci, a.B - 1);
+            const size_t base = (((size_t)clip * a.H + h) * a.T + min(tq, a.T - 1)) * a.Tk + 4 * q;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              pe[j] *= dropout_factor(a.p_attn, seed, base + j);
-              if constexpr (NKT == 2) pe[4 + j] *= dropout_factor(a.p_attn, seed, base + 16 + j);
-            }
-            pf.x = pack2<T>(pe[0], pe[1]);
-            pf.y = pack2<T>(pe[2], pe[3]);
-            if constexpr (NKT == 2) {
-              pf.z = pack2<T>(pe[4], pe[5]);
-              pf.w = pack2<T>(pe[6], pe[7]);
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                pe[ks][j] *= dropout_factor(a.p_attn, seed, base + 32 * ks + j);
+                if (2 * ks + 1 < NKT) pe[ks][4 + j] *= dropout_factor(a.p_attn, seed, base + 32 * ks + 16 + j);
+              }
+              pf[ks] = make_uint4(pack2<T>(pe[ks][0], pe[ks][1]), pack2<T>(pe[ks][2], pe[ks][3]), pack2<T>(pe[ks][4], pe[ks][5]),
+                                  pack2<T>(pe[ks][6], pe[ks][7]));
             }
           }
-          if (a.lse != nullptr && nt_blk == 0 && valid && q == 0 && 16 * qt + r < a.T) {
-            const int clip = rb * a.cpb + ci;
-            if (clip < a.B) a.lse[((size_t)clip * a.H + h) * a.T + 16 * qt + r] = m * a.scale + __logf(osum[0]);
+          if (a.lse != nullptr && nt_blk == 0 && valid && q == 0 && tq < a.T) {
+            const int clip = c0 + ci;
+            if (clip < a.B) a.lse[((size_t)clip * a.H + h) * a.T + tq] = m * a.scale + __logf(osum[0]);
           }
         }
         f32x4 o[DT];
-        // transposed 4-key x 16-column blocks: this lane supplies key row 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
-        const int vrow0 = ci * a.Tk + 4 * q + (r >> 2);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int col = h * DH + 16 * dt + 4 * (r & 3);
-          const char* p0a = v_img + vrow0 * rowb + (swz16(col >> 3, vrow0) << 4) + (((col >> 2) & 1) << 3);
-          const char* p1a = v_img + (vrow0 + 16) * rowb + (swz16(col >> 3, vrow0 + 16) << 4) + (((col >> 2) & 1) << 3);
-          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0a);
-          uint2 x1 = make_uint2(0u, 0u);
-          if constexpr (NKT == 2) x1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a));
-          const uint2 x0 = __builtin_bit_cast(uint2, v0);
-          o[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // transposed 4-key x 16-column blocks: this lane supplies key row 32 ks + 4 q + (r>>2) (+16), columns 16 dt + 4 (r&3)..
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int vrow0 = ci * a.Tk + 32 * ks + 4 * q + (r >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int col = h * DH + 16 * dt + 4 * (r & 3);
+            const char* p0a = v_img + vrow0 * rowb + (swz16(col >> 3, vrow0) << 4) + (((col >> 2) & 1) << 3);
+            const char* p1a = v_img + (vrow0 + 16) * rowb + (swz16(col >> 3, vrow0 + 16) << 4) + (((col >> 2) & 1) << 3);
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p0a);
+            uint2 x1 = make_uint2(0u, 0u);
+            if (2 * ks + 1 < NKT) x1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((VMC_LDS s16x4*)p1a));
+            const uint2 x0 = __builtin_bit_cast(uint2, v0);
+            o[dt] = T::mfma16(make_uint4(x0.x, x0.y, x1.x, x1.y), pf[ks], o[dt]);
+          }
         }
         const float inv = 1.0f / osum[0];
-        const int arow = ci * a.T + 16 * qt + r;   // row of the A image
-        if (valid && 16 * qt + r < a.T) {
+        const int arow = ci * a.T + 16 * qt + r;   // row of the A image (cpb == 1 whenever tq0 > 0 or T > 16)
+        if (valid && tq < a.T) {
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const int col = h * DH + 16 * dt + 4 * q;
@@ -586,19 +613,29 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
   tf_block_map(bid, a.n_tiles, a.n_rb, nt, rb);
   char* a_img = tf_smem;
   char* w_img = a_img + TF_BM * ROWB;
-  char* v_img = w_img + BN * ROWB;
+  // more than 32 keys: the V image (up to 64 rows x K) does not fit beside the W tile; W is staged into the SAME region once the
+  // attention prologue is done with V (one more exposed LDS-DMA latency, only for these shapes)
+  constexpr bool LATEW = PRO == PRO_ATTN && NKT > 2;
+  char* v_img = LATEW ? w_img : w_img + BN * ROWB;
   char* red = a_img;                             // K-slice exchange re-uses the A image once every wave is past its MFMAs
   const int n0 = nt * BN;
 
   if constexpr (PRO == PRO_ATTN) {
+    int c0, tq0;
+    tf_block_origin(a, rb, c0, tq0);
     TfAttnFrags<DH, QT, NKT, NW> fr;
-    tf_attn_load<DH, QT, NKT, NW>(a, fr, rb, wave * ((16 / NW) / QT), lane);
-    tf_attn_live(a, fr.livebits, rb, lane);
-    tf_stage_v(a, v_img, rb, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane, NW);
-    tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
+    tf_attn_load<DH, QT, NKT, NW>(a, fr, c0, tq0, wave * ((16 / NW) / QT), lane);
+    tf_attn_live(a, fr.livebits, c0, lane);
+    tf_stage_v(a, v_img, c0, (a.cpb - 1) * a.Tk + 16 * NKT, wave, lane, NW);
+    if constexpr (!LATEW) tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                             // V (and W) images complete
-    tf_pro_attn<T, DH, QT, NKT, NW, TR>(a, fr, a_img, v_img, rb, wave, lane, nt);
+    tf_pro_attn<T, DH, QT, NKT, NW, TR>(a, fr, a_img, v_img, c0, tq0, wave, lane, nt);
+    if constexpr (LATEW) {
+      __syncthreads();                           // every wave is done with the V image
+      tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
     tf_stage_w(a, w_img, n0, BN, wave, lane, NW);
     if constexpr (PRO == PRO_16) tf_pro_16(a, a_img, rb, wave, lane, NW);
@@ -612,8 +649,9 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
     // this block's BN columns of the attention output (saved for vmc_attention_bwd's delta and the out_proj weight gradient)
     if (a.oout != nullptr && tid < TF_BM * (BN / 8)) {
       const int row = tid / (BN / 8), c8 = (n0 >> 3) + tid % (BN / 8);
-      const int grow = rb * a.rpb + row;
-      if (row < a.rpb && grow < a.M && c8 * 8 < a.K)
+      bool rvalid;
+      const int grow = tf_grow(a, rb, row, rvalid);
+      if (rvalid && c8 * 8 < a.K)
         *(uint4*)(a.oout + (size_t)grow * a.K + c8 * 8) = *(const uint4*)(a_img + row * ROWB + (swz16(c8, row) << 4));
     }
   }
@@ -624,8 +662,9 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
 #pragma unroll
   for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int arow = 16 * rt + r;
-  const int grow_e = rb * a.rpb + arow;
-  const bool store_e = ks == 0 && arow < a.rpb && grow_e < a.M;
+  bool valid_e;
+  const int grow_e = tf_grow(a, rb, arow, valid_e);
+  const bool store_e = ks == 0 && valid_e;
   float4 rres[NTN];                              // TR: residual operand, prefetched under the MFMA loop
 #pragma unroll
   for (int n = 0; n < NTN; ++n) rres[n] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -680,8 +719,8 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
   }
   __syncthreads();
   if (ks == 0) {
-    const int lrow = 16 * rt + r, grow = rb * a.rpb + lrow;
-    if (lrow < a.rpb && grow < a.M) {
+    const int grow = grow_e;
+    if (valid_e) {
       int fclip = 0, ft = 0;
       if (EPI == EPI_ACT16 && a.frag_D > 0) {          // token coordinates of this lane's row: once, not per column tile
         fclip = grow / a.frag_T;
@@ -698,7 +737,7 @@ __device__ __forceinline__ void tf_gemm_body(const TfArgs& a, int bid, char* tf_
           const int fi = c0 / a.frag_D;
           if (fi < 2 && a.frag[fi] != nullptr) {      // a 16-column MFMA tile never straddles a head (head_dim % 16 == 0)
             const int c = c0 - fi * a.frag_D, head = c / a.frag_DH, d = c - head * a.frag_DH + 4 * q;
-            fdst = a.frag[fi] + tf_frag_off(fclip, head, ft, d, a.frag_H, a.frag_DH);
+            fdst = a.frag[fi] + tf_frag_off(fclip, head, ft, d, a.frag_H, a.frag_DH, a.frag_NTT > 0 ? a.frag_NTT : 2);
           }
         }
         if constexpr (TR) tf_epilogue_train<T, EPI>(a, grow, n0 + 16 * n + 4 * q, o, pre_added, fdst, rres[n]);
@@ -924,6 +963,10 @@ constexpr int TF_NW = 8;       // waves per workgroup of the single-shot kernels
 
 template <int BN, int PRO, int KD, int NKT>
 constexpr size_t tf_lds_bytes(int cpb, int Tk) {
+  if (PRO == PRO_ATTN && NKT > 2) {              // V and W share a region (LATEW)
+    const size_t v = (size_t)((cpb - 1) * Tk + 16 * NKT) * KD * 2 + 1024, w = (size_t)BN * KD * 2;
+    return (size_t)TF_BM * KD * 2 + (v > w ? v : w);
+  }
   return (size_t)(TF_BM + BN) * KD * 2 +
          (PRO == PRO_ATTN ? (size_t)((cpb - 1) * Tk + 16 * NKT) * KD * 2 + 1024 : 0);    // + one LDS-DMA piece of slack
 }
@@ -944,7 +987,7 @@ int tf_launch(TfArgs& a, hipStream_t s) {
   if (lds > TF_LDS_MAX || a.K != KD) return VMC_E_SHAPE;
   if ((TF_NW / 2 - 1) * 2 * (BN / 16) * 1024 > TF_BM * KD * 2) return VMC_E_SHAPE;      // K-slice exchange must fit the A image
   a.n_tiles = (a.N + BN - 1) / BN;
-  a.n_rb = (a.M + a.rpb - 1) / a.rpb;
+  a.n_rb = (PRO == PRO_ATTN && a.parts > 1) ? a.B * a.parts : (a.M + a.rpb - 1) / a.rpb;
   auto kern = tf_gemm_kernel<T, BN, PRO, EPI, KD, DH, QT, NKT, TF_NW, TR>;
   static bool attr_done = false;                // per instantiation
   if (int rc = tf_set_lds(kern, attr_done)) return rc;
@@ -993,7 +1036,9 @@ inline int tf_pick_bn(int M, int N, int rpb, int K, bool attn, int vrows = 48) {
     const int bn = cands[i];
     if (N % bn && !(N < bn)) continue;
     if (attn && bn > 32) break;
-    const size_t lds = (size_t)(TF_BM + bn) * K * 2 + (attn ? (size_t)vrows * K * 2 + 1024 : 0);
+    if (attn && vrows > 48 && bn > 16) break;    // more than 32 keys: the 16-column kernels (V and W share a region)
+    const size_t lds = (attn && vrows > 48) ? (size_t)TF_BM * K * 2 + (size_t)vrows * K * 2 + 1024
+                                             : (size_t)(TF_BM + bn) * K * 2 + (attn ? (size_t)vrows * K * 2 + 1024 : 0);
     if (lds > TF_LDS_MAX) break;
     best = bn;
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -1019,7 +1064,11 @@ int tf_dispatch_bn(TfArgs& a, int bn, hipStream_t s) {
 
 template <typename T, int KD, int BN, int DH>
 int tf_dispatch_attn3(TfArgs& a, hipStream_t s) {
-  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 16 ? 2 : 1;
+  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 32 ? 4 : (a.Tk > 16 ? 2 : 1);
+  if (nkt == 4) {
+    if constexpr (BN == 16) return qt == 1 ? tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 1, 4>(a, s) : tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 2, 4>(a, s);
+    else return VMC_E_SHAPE;
+  }
   if (qt == 1 && nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 1>(a, s);
   if (qt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 1, 2>(a, s);
   if (nkt == 1) return tf_launch<T, BN, PRO_ATTN, EPI_RESID32, KD, DH, 2, 1>(a, s);
@@ -1037,13 +1086,13 @@ struct TfDims {
 };
 
 inline int tf_check(const TfDims& d) {
-  if (d.B <= 0 || d.T <= 0 || d.T > 32 || d.L <= 0 || d.C <= 0) return VMC_E_SHAPE;
+  if (d.B <= 0 || d.T <= 0 || d.T > TF_MAX_T || d.L <= 0 || d.C <= 0) return VMC_E_SHAPE;
   if (d.D != 512 && d.D != 768) return VMC_E_SHAPE;
   if (d.H <= 0 || d.D % d.H) return VMC_E_SHAPE;
   const int dh = d.D / d.H;
   if (dh != 64 && dh != 96) return VMC_E_SHAPE;
   if (d.ff % 512 || d.ff <= 0) return VMC_E_SHAPE;
-  if (d.has_cross && (d.Tk <= 0 || d.Tk > 32)) return VMC_E_SHAPE;
+  if (d.has_cross && (d.Tk <= 0 || d.Tk > TF_MAX_T)) return VMC_E_SHAPE;
   const int cpb = d.T <= 16 ? 2 : 1;
   if ((cpb * d.H) % 4) return VMC_E_SHAPE;
   return 0;

@@ -138,7 +138,7 @@ inline TrWs tr_ws(void* base, const TrDims& d) {
   size_t o = 0;
   auto take = [&](size_t n) { char* q = p + o; o += tr_al(n); return q; };
   w.motion16 = (uint16_t*)take(Mk * D * 2);
-  const size_t fe = tf_frag_elems(d.B, d.H, d.D / d.H);
+  const size_t fe = tf_frag_elems(d.B, d.H, d.D / d.H, tf_ntt(d.T > d.Tk ? d.T : d.Tk));
   w.qf = (uint16_t*)take(fe * 2);
   w.kf = (uint16_t*)take(fe * 2);
   w.kxf = (uint16_t*)take(fe * 2);
@@ -201,7 +201,8 @@ int tr_gemm(TfArgs& a, hipStream_t s) {
 }
 template <typename T, int KD, int DH>
 int tr_attn3(TfArgs& a, hipStream_t s) {
-  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 16 ? 2 : 1;
+  const int qt = a.T > 16 ? 2 : 1, nkt = a.Tk > 32 ? 4 : (a.Tk > 16 ? 2 : 1);
+  if (nkt == 4) return qt == 1 ? tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 1, 4, true>(a, s) : tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 2, 4, true>(a, s);
   if (qt == 1 && nkt == 1) return tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 1, 1, true>(a, s);
   if (qt == 1) return tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 1, 2, true>(a, s);
   if (nkt == 1) return tf_launch<T, 16, PRO_ATTN, EPI_RESID32, KD, DH, 2, 1, true>(a, s);
@@ -237,7 +238,7 @@ template <typename T>
 int tr_layer_fwd(const float* x_in, const float* motion, const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_layer_params* layers,
                  int layer, const TrDims& d, const TrWs& ws, float p, const uint64_t* seeds, hipStream_t s) {
   const int M = d.B * d.T, D = d.D, dh = D / d.H;
-  const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
+  const int cpb = d.T <= 16 ? 2 : 1, parts = d.T > 32 ? (d.T + 31) / 32 : 1, rpb = d.T > 32 ? 32 : cpb * d.T;
   const float scale = 1.0f / sqrtf((float)dh);
   const vmc_tfam_layer_params& P = layers[layer];
   const TrLayerWs w = tr_lw(ws, d, layer);
@@ -249,14 +250,14 @@ int tr_layer_fwd(const float* x_in, const float* motion, const uint8_t* mask, co
     a.M = M; a.N = 3 * D; a.K = D; a.rpb = rpb;
     a.W = (const uint16_t*)P.w_self_in; a.ldw = D; a.bias = P.b_self_in;
     a.out = w.qkv16; a.ldo = 3 * D; a.act = VMC_ACT_NONE;
-    a.frag[0] = ws.qf; a.frag[1] = ws.kf; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;
+    a.frag[0] = ws.qf; a.frag[1] = ws.kf; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh; a.frag_NTT = tf_ntt(d.T);
     a.x16out = w.x0_16;
     TfArgs b = {};
     if (d.has_cross) {
       b.A = motion; b.lda = D; b.M = d.B * d.Tk; b.N = 2 * D; b.K = D; b.rpb = 32;
       b.W = (const uint16_t*)P.w_cross_in + (size_t)D * D; b.ldw = D; b.bias = P.b_cross_in + D;
       b.out = w.kv16; b.ldo = 2 * D; b.act = VMC_ACT_NONE;
-      b.frag[0] = ws.kxf; b.frag[1] = nullptr; b.frag_D = D; b.frag_T = d.Tk; b.frag_H = d.H; b.frag_DH = dh;
+      b.frag[0] = ws.kxf; b.frag[1] = nullptr; b.frag_D = D; b.frag_T = d.Tk; b.frag_H = d.H; b.frag_DH = dh; b.frag_NTT = tf_ntt(d.Tk);
       b.x16out = layer == 0 ? ws.motion16 : nullptr;
     }
     if (layer == 0) {
@@ -276,6 +277,7 @@ int tr_layer_fwd(const float* x_in, const float* motion, const uint8_t* mask, co
     TfArgs a = {};
     a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
     a.q = ws.qf; a.k = ws.kf; a.v = w.qkv16 + 2 * D; a.ldv = 3 * D;
+    a.parts = parts; a.ntt_q = a.ntt_k = tf_ntt(d.T);
     a.kmask = mask; a.T = d.T; a.Tk = d.T; a.H = d.H; a.B = d.B; a.scale = scale;
     a.W = (const uint16_t*)P.w_self_out; a.ldw = D; a.bias = P.b_self_out;
     a.resid = resid; a.ldres = D; a.out = w.y1; a.ldo = D;
@@ -292,13 +294,14 @@ int tr_layer_fwd(const float* x_in, const float* motion, const uint8_t* mask, co
       a.A = w.y1; a.lda = D; a.eps = 1e-5f; a.ln_g = lng; a.ln_b = lnb; a.ln_affine = 1; a.xout = w.x1_32; a.x16out = w.x1_16;
       a.W = (const uint16_t*)P.w_cross_in; a.ldw = D; a.bias = P.b_cross_in;
       a.out = w.q16; a.ldo = D; a.act = VMC_ACT_NONE;
-      a.frag[0] = ws.qf; a.frag[1] = nullptr; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh;
+      a.frag[0] = ws.qf; a.frag[1] = nullptr; a.frag_D = D; a.frag_T = d.T; a.frag_H = d.H; a.frag_DH = dh; a.frag_NTT = tf_ntt(d.T);
       if ((rc = tr_gemm<T, PRO_LN, EPI_ACT16>(a, s))) return rc;
     }
     {  // F4: y2 = x1 + drop(crossattn(q, K, V) Wo^T + b)
       TfArgs a = {};
       a.M = M; a.N = D; a.K = D; a.rpb = rpb; a.cpb = cpb;
       a.q = ws.qf; a.k = ws.kxf; a.v = w.kv16 + D; a.ldv = 2 * D;
+      a.parts = parts; a.ntt_q = tf_ntt(d.T); a.ntt_k = tf_ntt(d.Tk);
       a.kmask = mask_kv; a.T = d.T; a.Tk = d.Tk; a.H = d.H; a.B = d.B; a.scale = scale;
       a.W = (const uint16_t*)P.w_cross_out; a.ldw = D; a.bias = P.b_cross_out;
       a.resid = w.x1_32; a.ldres = D; a.out = w.y2; a.ldo = D;
@@ -670,7 +673,7 @@ template <typename T>
 int tr_layer_bwd(const uint8_t* mask, const uint8_t* mask_kv, const vmc_tfam_layer_params* layers, int layer, const TrDims& d, const TrWs& ws,
                  float p, const uint64_t* seeds, int dtype16, hipStream_t s, TrWgradGroup* defer = nullptr) {
   const int M = d.B * d.T, Mk = d.B * d.Tk, D = d.D, dh = D / d.H;
-  const int cpb = d.T <= 16 ? 2 : 1, rpb = cpb * d.T;
+  const int rpb = d.T > 32 ? 32 : (d.T <= 16 ? 2 : 1) * d.T;      // the backward's GEMMs are all row-wise: uniform blocks
   const vmc_tfam_layer_params& P = layers[layer];
   const TrLayerWs w = tr_lw(ws, d, layer);
   const bool drop = p > 0.f;

@@ -24,7 +24,7 @@ W_SELF_IN, W_SELF_OUT, W_CROSS_Q, W_CROSS_OUT, W_FFN0, W_FFN3, W_KV_ALL, W_CLS1,
 (P_SELF_IN_B, P_SELF_OUT_B, P_CROSS_Q_B, P_CROSS_OUT_B, P_FFN0_B, P_FFN3_B, P_NORM_SELF, P_NORM_CROSS, P_NORM_FFN,
  P_KV_ALL_B, P_CLS_LN, P_CLS1_B, P_CLS4_B, P_END) = range(16, 30)
 
-MAX_T = 32
+MAX_T = 64        # tokens per clip (TF_MAX_T of csrc/tfam_kernels.h): queries in parts of 32 per row block, up to four key tiles
 MAX_ROWS = 256      # B*T above which the per-op path (256x256 GEMM tiles) wins: measured crossover B = 16 at T = 16 (profiles/README.md)
 
 
