@@ -250,7 +250,7 @@ def tfam_forward_block(dev, rank, cdt, batches=(8, 16, 64), iters=200):
         if B == 8:
             # throughput with several independent batches in flight (an evaluation loop: batches do not depend on each other):
             # one graph + one scratch slot per stream, replayed round-robin; a launch's fixed ~4 us overlaps the other streams' work
-            for nfl in (2, 4):
+            for nfl in (2, 4, 8):
                 streams = [torch.cuda.Stream() for _ in range(nfl)]
                 graphs = []
                 for i, st in enumerate(streams):
@@ -268,7 +268,10 @@ def tfam_forward_block(dev, rank, cdt, batches=(8, 16, 64), iters=200):
                 torch.cuda.synchronize()
                 t_in = (time.perf_counter() - t0) / (reps * nfl)
                 row[f"fused_chain_{nfl}_in_flight"] = {"us_per_forward": round(t_in * 1e6, 2), "clips_per_s": round(B / t_in, 1),
-                                                       "note": "weights served by L2 / Infinity Cache across the concurrent forwards"}
+                                                       "hbm_frac_per_forward": round(tfam_hbm_bytes(B)[0] / t_in / 8e12, 4),
+                                                       "note": "weights served by L2 / Infinity Cache across the concurrent forwards; hipGraph replays on "
+                                                               "different streams do not scale past two on this runtime (four with GPU_MAX_HW_QUEUES=8, "
+                                                               "collapse at eight): profiles/README.md round 3"}
                 del graphs
         row["bytes_fwd"] = tfam_hbm_bytes(B)[0]
         out[f"B{B}"] = row
