@@ -704,14 +704,14 @@ def main():
             achieved = f_big / t_big / 1e12 if big else 0.0
             traffic = None
             try:    # HBM bytes per launch of the c_fc shape from the committed rocprofv3 --pmc passes (cannot be collected in-process)
-                with open(os.path.join(ROOT, "profiles", "r02_gemm8_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r03_gemm8_traffic.json")) as f:
                     traffic = json.load(f)["hbm_bytes_per_launch"]
             except Exception:
                 pass
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE of one [65792,1024]x[1024,4096] launch (profiles/r02_gemm8_traffic.json); algorithmic bytes 6.8e8",
+                "traffic_note": "PMC FETCH_SIZE x2 + WRITE_SIZE of one [65792,1024]x[1024,4096] launch (profiles/r03_gemm8_traffic.json); algorithmic bytes 6.8e8",
                 "kernel": "gemm8p_kernel<BF16,*> (vmc_linear: persistent walk of 8-phase 256x256x64 tiles; gemm8_kernel for the few non-eligible launches), all large-GEMM launches of the step", "launches": len(big),
                 "avg_launch_ms": round(1e3 * t_big / max(1, len(big)), 4),
                 "note": "algorithmic FLOPs = 2*M*N*K (K incl. zero padding 588->640 of the patch GEMM) per launch",
