@@ -297,6 +297,20 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
   // so the grid still covers the 256 CUs (TFAM/head GEMMs have M = B*16 or B rows).
   const long t256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
   const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if constexpr (ACT == VMC_ACT_NONE) {      // builder A/B switch for the mid-size regime (profiles/README.md round 3)
+    static const int force = getenv("VMC_GEMM_CFG") ? atoi(getenv("VMC_GEMM_CFG")) : 0;
+    switch (force) {
+      case 1: return launch_cfg<T, ACT, 4, 2, 2, 3>(g, stream);      // 128 x 128, 3-stage ring
+      case 2: return launch_cfg<T, ACT, 4, 2, 2, 4>(g, stream);      // 128 x 128, 4-stage ring
+      case 3: return launch_cfg<T, ACT, 4, 2, 1, 4>(g, stream);      // 128 x 64, 4-stage ring
+      case 4: return launch_cfg<T, ACT, 2, 2, 2, 4>(g, stream);      // 64 x 128, 4-stage ring
+      case 5: return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);      // 64 x 64, 4-stage ring
+      case 6: return launch_cfg<T, ACT, 4, 2, 2>(g, stream);         // 128 x 128, two stages (today's mid-size kernel)
+      case 7: return launch_cfg<T, ACT, 4, 2, 1, 6>(g, stream);      // 128 x 64, 6-stage ring
+      case 8: return launch_cfg<T, ACT, 2, 2, 2, 6>(g, stream);      // 64 x 128, 6-stage ring
+      default: break;
+    }
+  }
   if (t256 >= 192) return launch_cfg<T, ACT, 8, 2, 4>(g, stream);
   if (t128 >= 128) return launch_cfg<T, ACT, 4, 2, 2>(g, stream);
   // 64x64 tiles: latency-bound -> 4-stage ring.  A workgroup streams its (BM + 64) x K operand bytes at the ~70 GB/s one CU pulls
