@@ -81,3 +81,24 @@ def test_persistent_gemm_kernels_use_no_scratch():
         spills = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         assert scratch == 0 and spills == 0, (name, scratch, spills)
     assert seen >= 10, seen
+
+
+def test_training_parameter_structs_mirror_the_header():
+    """vmc_tfam_layer_params / vmc_tfam_head_params (include/vmc.h) are filled from Python through ctypes.Structure mirrors
+    (vimo_clip_amd/tfam_train.py): same field names in the same order, every field one pointer wide."""
+    import ctypes as C
+
+    from vimo_clip_amd import tfam_train as tt
+    src = open(os.path.join(ROOT, "include", "vmc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for cname, mirror in (("vmc_tfam_layer_params", tt.LayerParams), ("vmc_tfam_head_params", tt.HeadParams)):
+        body = re.search(r"typedef struct " + cname + r"\s*\{(.*?)\}\s*" + cname + r"\s*;", src, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            assert re.match(r"(const\s+)?(void|float)\s*\*", decl), decl          # pointers only
+            names += [n.strip().lstrip("*").strip() for n in re.sub(r"^(const\s+)?(void|float)\s*", "", decl).split(",")]
+        assert names == [f[0] for f in mirror._fields_], (cname, names)
+        assert all(f[1] is C.c_void_p for f in mirror._fields_) and C.sizeof(mirror) == 8 * len(names)
