@@ -139,7 +139,9 @@ int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbi
  * VMC_GEMM_NO_TAIL_SPLIT = the same without that split, VMC_GEMM_PERSISTENT = the persistent walk for every eligible
  * epilogue, VMC_GEMM_ONE_TILE = never persistent (one tile per workgroup).  Results are identical bit for bit across them. */
 enum { VMC_GEMM_TWOSTAGE = 0, VMC_GEMM_DEFAULT = 1, VMC_GEMM_NO_TAIL_SPLIT = 2, VMC_GEMM_PERSISTENT = 3, VMC_GEMM_ONE_TILE = 4,
-       VMC_GEMM_VARIANTS = 5 };
+       VMC_GEMM_MFMA32 = 5, /* the persistent walk on v_mfma_f32_32x32x16 fragments (bias / QuickGELU / bias-free epilogues); the
+                               k-steps are summed 16 at a time, so the last bit may differ from the other variants */
+       VMC_GEMM_VARIANTS = 6 };
 int vmc_linear_variant(const void* A, const void* W, const float* bias, const void* res, void* C,
                        int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                        int act, float alpha, int out_dtype, int res_dtype, int out_row_group, int res_row_mod,

@@ -236,6 +236,67 @@ static void test_gemm8() {
   }
 }
 
+// v_mfma_f32_32x32x16: first operand lane l holds A[row l&31][k = 8(l>>5)+j], second B[k = 8(l>>5)+j][col l&31];
+// accumulator reg i of lane l is D[row 8(i>>2) + 4(l>>5) + (i&3)][col l&31]
+static void mfma32(const Frag a[64], const Frag b[64], long acc[64][16]) {
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * (i >> 2) + 4 * (l >> 5) + (i & 3), col = l & 31;
+      long s = 0;
+      for (int k = 0; k < 16; ++k) s += (long)a[(k / 8) * 32 + row].v[k % 8] * (long)b[(k / 8) * 32 + col].v[k % 8];
+      acc[l][i] += s;
+    }
+}
+
+// the 8-phase tile on 32x32x16 fragments (same LDS images and staging as test_gemm8)
+static void test_gemm8_mfma32() {
+  std::vector<e16> A(256 * 64), W(256 * 64);
+  for (auto& x : A) x = (e16)(rand() % 7 - 3);
+  for (auto& x : W) x = (e16)(rand() % 7 - 3);
+  std::vector<uint8_t> slot[4];  // A0 A1 B0 B1
+  for (auto& s : slot) s.assign(16384, 0xEE);
+  for (int tid = 0; tid < 512; ++tid)
+    for (int i = 0; i < 2; ++i) {
+      int row, ch;
+      stage_src_x(i * 512 + tid, row, ch);
+      memcpy(&slot[0][(size_t)(i * 512 + tid) * 16], &A[row * 64 + ch * 8], 16);
+      memcpy(&slot[1][(size_t)(i * 512 + tid) * 16], &A[(128 + row) * 64 + ch * 8], 16);
+      stage_src_w8(i * 512 + tid, row, ch);
+      memcpy(&slot[2][(size_t)(i * 512 + tid) * 16], &W[row * 64 + ch * 8], 16);
+      memcpy(&slot[3][(size_t)(i * 512 + tid) * 16], &W[(128 + row) * 64 + ch * 8], 16);
+    }
+  for (int wave = 0; wave < 8; ++wave) {
+    const int wm = wave >> 2, wn = wave & 3;
+    for (int mh = 0; mh < 2; ++mh) for (int nh = 0; nh < 2; ++nh)
+      for (int mt = 0; mt < 2; ++mt) {
+        long acc[64][16]; memset(acc, 0, sizeof acc);
+        for (int kk = 0; kk < 4; ++kk) {
+          Frag wf[64], xf[64]; int xaddr[64], waddr[64];
+          for (int l = 0; l < 64; ++l) {
+            const int x = l & 31, h = l >> 5;
+            // the kernel forms the k-step address as (offset of k-step 0) XOR (kk << 5), A row tiles by an immediate
+            xaddr[l] = (lds_off_x(64 * wm + x, h) ^ (kk << 5)) + mt * 4096;
+            waddr[l] = lds_off_w8(32 * wn + g8_w_row32(x), h) ^ (kk << 5);
+            CHECK(xaddr[l] == lds_off_x(64 * wm + 32 * mt + x, 2 * kk + h), "g8/32 X address form");
+            CHECK(waddr[l] == lds_off_w8(32 * wn + g8_w_row32(x), 2 * kk + h), "g8/32 W address form");
+            memcpy(xf[l].v, &slot[mh][xaddr[l]], 16);
+            memcpy(wf[l].v, &slot[2 + nh][waddr[l]], 16);
+          }
+          CHECK(b128_conflict(xaddr) == 1, "g8/32 X read conflict %d", b128_conflict(xaddr));
+          CHECK(b128_conflict(waddr) == 1, "g8/32 W read conflict %d", b128_conflict(waddr));
+          mfma32(wf, xf, acc);
+        }
+        for (int l = 0; l < 64; ++l) for (int i = 0; i < 16; ++i) {
+          const int x = l & 31, h = l >> 5;
+          const int row = 128 * mh + 64 * wm + 32 * mt + x, col = 128 * nh + 32 * wn + g8_c_col32(h, i);
+          long ref = 0;
+          for (int k = 0; k < 64; ++k) ref += (long)A[row * 64 + k] * W[col * 64 + k];
+          CHECK(acc[l][i] == ref, "g8/32 wave %d mh %d nh %d mt %d lane %d i %d", wave, mh, nh, mt, l, i);
+        }
+      }
+  }
+}
+
 static void test_xcd_remap() {
   for (int nwg : {1, 7, 8, 9, 63, 64, 100, 1028, 3084}) {
     std::set<int> seen;
@@ -250,6 +311,7 @@ int main() {
   test_gemm(4, 2, 2);
   test_gemm(2, 2, 1);
   test_gemm8();
+  test_gemm8_mfma32();
   test_attention(18, 257);
   test_attention(4, 50);
   test_attention(2, 17);

@@ -92,6 +92,32 @@ def test_linear_persistent_walk(ops, dtype, M, N, K, act):
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,act", [(16384, 4096, 384, 1), (8192, 8192, 1024, 0), (21760, 768, 768, 0)])
+def test_linear_persistent_walk_mfma32(ops, dtype, M, N, K, act):
+    """The persistent walk on 32x32x16 MFMA fragments (VMC_GEMM_MFMA32; kept as the measured, slower alternative of DESIGN 3.1):
+    integer operands exact, random operands equal to the 16x16x32 form (they agree bit for bit on this hardware) on repeats."""
+    if act == 0:
+        a = _ints((M, K), -1, 1, 21)
+        w = _ints((N, K), -1, 1, 22)
+        w[:, 0] += torch.arange(N).float() % 3
+        bias = (torch.arange(N).float() % 7) - 3
+        z = a.to(DEV) @ w.to(DEV).t() + bias.to(DEV)
+        assert z.abs().max().item() <= 256
+        out = ops.linear(a.to(DEV, dtype), w.to(DEV, dtype), bias=bias.to(DEV), out_dtype=dtype, variant=5)
+        assert torch.equal(out.float(), z), f"max diff {(out.float() - z).abs().max()}"
+    g = torch.Generator(device=DEV).manual_seed(M + K + 5)
+    ar = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    wr = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(dtype)
+    br = torch.randn(N, device=DEV, generator=g)
+    ref = ops.linear(ar, wr, bias=br, act=act, alpha=0.75, out_dtype=dtype)
+    for _ in range(3):
+        assert torch.equal(ops.linear(ar, wr, bias=br, act=act, alpha=0.75, out_dtype=dtype, variant=5), ref)
+    if act == 0:
+        ref = ops.linear(ar, wr, out_dtype=dtype)
+        assert torch.equal(ops.linear(ar, wr, out_dtype=dtype, variant=5), ref)
+
+
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 @pytest.mark.parametrize("res_f32,out_f32", [(True, True), (False, False), (True, False)])
 @pytest.mark.parametrize("shape", [(333, 200, 128), (3900, 4096, 256)], ids=["small", "g8"])

@@ -577,6 +577,237 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   if (wm == 0) __builtin_amdgcn_s_barrier();        // balance the stagger barrier
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The persistent walk on v_mfma_f32_32x32x16 fragments (VERDICT r2 item 6 i): same tile, LDS images, staging, barriers and vmcnt
+// accounting (4 / 8 stores per quadrant and wave, as the 16x16x32 form); 8 MFMAs of 32 cycles per phase instead of 16 of 16, i.e.
+// half the operand-register reads per FLOP.  Lane (x = lane & 31, h = lane >> 5); fragment maps in tile_index.h (g8_w_row32).
+template <typename T>
+struct G8Frags32 {
+  uint4 a[2][4];   // [mt][kk] current A half (64 rows of this wave as two 32-row tiles, four k-steps of 16)
+  uint4 b0[4];     // [kk] B half 0 (this wave's 32 columns)
+  uint4 b1[4];
+};
+// k-step kk of a fragment = logical chunk 2 kk + h = (2 kk) ^ h, so its swizzled offset is (offset of k-step 0) ^ (kk << 5)
+__device__ __forceinline__ void g8_read_a32(const char* slot, int xoff0, uint4 (&a)[2][4]) {
+  const uint32_t base = lds_addr(slot);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint32_t ad = base + (uint32_t)(xoff0 ^ (kk << 5));
+    lds_read128<0>(a[0][kk], ad);
+    lds_read128<4096>(a[1][kk], ad);
+  }
+}
+__device__ __forceinline__ void g8_read_b32(const char* slot, int woff0, uint4 (&b)[4]) {
+  const uint32_t base = lds_addr(slot);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) lds_read128<0>(b[kk], base + (uint32_t)(woff0 ^ (kk << 5)));
+}
+template <typename T>
+__device__ __forceinline__ void g8_mma32(f32x16 (&acc)[2], const uint4 (&a)[2][4], const uint4 (&b)[4]) {
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = T::mfma32(b[kk], a[mt][kk], acc[mt]);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+}
+
+// quadrant epilogue: lane (x, h) holds rows 32 mt + x, columns 8 h + [0, 8) (registers 0..7) and 16 + 8 h + [0, 8) (8..15) of the
+// wave's 64 x 32 window: 2 x 2 sixteen-byte stores, 32 contiguous bytes per row and instruction
+template <typename T, int ACT, bool BIAS, bool ZOUT, int MH, int NH>
+__device__ __forceinline__ void g8p_fin_quadrant32(const GemmArgs& g, f32x16 (&aq)[2], char* ctile, char* ztile, uint32_t clane,
+                                                   uint32_t bias_ad) {
+  float bv[16];
+  if constexpr (BIAS) {
+    uint4 braw[4];
+    lds_read128<512 * NH>(braw[0], bias_ad);
+    lds_read128<512 * NH + 16>(braw[1], bias_ad);
+    lds_read128<512 * NH + 64>(braw[2], bias_ad);
+    lds_read128<512 * NH + 80>(braw[3], bias_ad);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bv[4 * i + 0] = __uint_as_float(braw[i].x); bv[4 * i + 1] = __uint_as_float(braw[i].y);
+      bv[4 * i + 2] = __uint_as_float(braw[i].z); bv[4 * i + 3] = __uint_as_float(braw[i].w);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+  }
+  uint32_t cl = clane;
+  asm volatile("" : "+v"(cl));
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = aq[mt][8 * o + j] + bv[8 * o + j];
+      const uint32_t off = cl + (uint32_t)(128 * MH + 32 * mt) * (uint32_t)g.ldc * 2u + 256u * NH + 32u * o;
+      if constexpr (ZOUT)
+        *(uint4*)(ztile + off) = make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
+      g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
+                  (uint16_t*)(ctile + off));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) aq[mt][j] = 0.f;
+  }
+}
+
+template <typename T, int ACT, bool BIAS, bool ZOUT, int KIND>
+__device__ __forceinline__ void g8p_iter32(const GemmArgs& g, char* __restrict__ A0e, char* __restrict__ A1e, char* __restrict__ B0e,
+                                           char* __restrict__ B1e, char* __restrict__ A0o, char* __restrict__ A1o,
+                                           char* __restrict__ B0o, char* __restrict__ B1o, const __amdgpu_buffer_rsrc_t ra,
+                                           const __amdgpu_buffer_rsrc_t rb, const G8Panel& p1, const G8Panel& p2,
+                                           const G8Panel& p3, uint32_t HA, uint32_t HB, const uint32_t (&oa)[2], const uint32_t (&ob)[2],
+                                           int wave_lds, int xoff, int woff, f32x16 (&acc)[2][2][2], G8Frags32<T>& f, bool pending,
+                                           char* fin_c, char* fin_z, uint32_t clane, uint32_t fin_b) {
+  constexpr int QS = ZOUT ? 8 : 4, NB = BIAS ? 1 : 0;
+  // ---- even tile ----
+  g8_read_b32(B0e, woff, f.b0); g8_read_a32(A0e, xoff, f.a);
+  g8p_stage(rb, B1o, p1.b + HB, ob, wave_lds);
+  if (KIND == G8P_HEAD && pending) g8p_fin_quadrant32<T, ACT, BIAS, ZOUT, 1, 0>(g, acc[1][0], fin_c, fin_z, clane, fin_b);
+  g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 4 * QS>(pending);
+  g8_mma32<T>(acc[0][0], f.a, f.b0);
+  g8_read_b32(B1e, woff, f.b1);
+  g8p_stage(ra, A1o, p1.a + HA, oa, wave_lds); g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 4 * QS>(pending);
+  g8_mma32<T>(acc[0][1], f.a, f.b1);
+  g8_read_a32(A1e, xoff, f.a);
+  g8p_stage(ra, A0e, p2.a, oa, wave_lds);
+  g8_mma32<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0e, p2.b, ob, wave_lds); g8p_wait<KIND, 8, 8, 8 + NB, 8 + NB + 2 * QS>(pending);
+  g8_mma32<T>(acc[1][0], f.a, f.b0);
+  // ---- odd tile ----
+  g8_read_b32(B0o, woff, f.b0); g8_read_a32(A0o, xoff, f.a);
+  g8p_stage(rb, B1e, p2.b + HB, ob, wave_lds); g8p_wait<KIND, 8, 8, 8, 8 + QS>(pending);
+  g8_mma32<T>(acc[0][0], f.a, f.b0);
+  g8_read_b32(B1o, woff, f.b1);
+  g8p_stage(ra, A1e, p2.a + HA, oa, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant32<T, ACT, BIAS, ZOUT, 0, 0>(g, acc[0][0], fin_c, fin_z, clane, fin_b);
+  g8p_wait<KIND, 8, 8 + QS, 8, 8>(pending);
+  g8_mma32<T>(acc[0][1], f.a, f.b1);
+  g8_read_a32(A1o, xoff, f.a);
+  g8p_stage(ra, A0o, p3.a, oa, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant32<T, ACT, BIAS, ZOUT, 0, 1>(g, acc[0][1], fin_c, fin_z, clane, fin_b);
+  g8_mma32<T>(acc[1][1], f.a, f.b1);
+  g8p_stage(rb, B0o, p3.b, ob, wave_lds);
+  if constexpr (KIND == G8P_ROLL) g8p_fin_quadrant32<T, ACT, BIAS, ZOUT, 1, 1>(g, acc[1][1], fin_c, fin_z, clane, fin_b);
+  g8p_wait<KIND, 8, 8 + 3 * QS, 8, 8>(pending);
+  g8_mma32<T>(acc[1][0], f.a, f.b0);
+}
+
+template <typename T, int ACT, bool BIAS, bool ZOUT>
+__global__ void __launch_bounds__(512, 2) gemm8p32_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int x = lane & 31, h = lane >> 5;
+  const int ntiles = g.tiles_m * g.tiles_n;
+
+  uint32_t oa[2], ob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, ch;
+    stage_src_x(i * 512 + tid, row, ch);
+    oa[i] = (uint32_t)(row * g.lda + ch * 8) * 2u;
+    stage_src_w8(i * 512 + tid, row, ch);
+    ob[i] = (uint32_t)(row * g.ldw + ch * 8) * 2u;
+  }
+  const uint32_t HA = 128u * (uint32_t)g.lda * 2u, HB = 128u * (uint32_t)g.ldw * 2u;
+  const uint32_t TA = 2 * HA, TB = 2 * HB;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? g.bias : (const float*)g.W), 0, g.N * 4, 0x00020000);
+  const int wave_lds = wave * 1024;
+  const int xoff = lds_off_x(64 * wm + x, h), woff = lds_off_w8(32 * wn + g8_w_row32(x), h);
+  char* const A0e = smem + 0 * G8_SLOT; char* const A1e = smem + 1 * G8_SLOT;
+  char* const B0e = smem + 2 * G8_SLOT; char* const B1e = smem + 3 * G8_SLOT;
+  char* const A0o = smem + 4 * G8_SLOT; char* const A1o = smem + 5 * G8_SLOT;
+  char* const B0o = smem + 6 * G8_SLOT; char* const B1o = smem + 7 * G8_SLOT;
+  char* const bias_lds = smem + 8 * G8_SLOT;
+  const uint32_t bias_lane = (uint32_t)lane * 4u;
+  const uint32_t bias_ad0 = lds_addr(bias_lds) + (uint32_t)(32 * wn + 8 * h) * 4u;
+  const uint32_t clane = ((uint32_t)(64 * wm + x) * (uint32_t)g.ldc + 32 * wn + 8 * h) * 2u;   // also the side output's (ldz == ldc)
+
+  const int nkt = g.K >> 6;   // even, >= 4 (checked by the launcher)
+  int bid = blockIdx.x, tm, tn;
+  if (bid >= ntiles) return;
+  g8_tile_coords(g, xcd_remap(bid, ntiles), tm, tn);
+  G8Panel cur = {(uint32_t)tm * TA, (uint32_t)tn * TB};
+  g8p_stage(ra, A0e, cur.a, oa, wave_lds); g8p_stage(rb, B0e, cur.b, ob, wave_lds); g8p_stage(rb, B1e, cur.b + HB, ob, wave_lds);
+  g8p_stage(ra, A1e, cur.a + HA, oa, wave_lds); g8p_stage(ra, A0o, cur.a + 128, oa, wave_lds); g8p_stage(rb, B0o, cur.b + 128, ob, wave_lds);
+  G8_WAIT8();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave of every SIMD by one barrier
+
+  f32x16 acc[2][2][2];  // [mh][nh][mt]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[a][b][c][j] = 0.f;
+
+  G8Frags32<T> f;
+  int parity = 0;
+  char* prev_c = nullptr;
+  char* prev_z = nullptr;
+  uint32_t prev_b = bias_ad0;
+  for (;;) {
+    const int nbid = bid + (int)gridDim.x;
+    const bool has_next = nbid < ntiles;
+    int ntm = tm, ntn = tn;
+    if (has_next) g8_tile_coords(g, xcd_remap(nbid, ntiles), ntm, ntn);
+    const G8Panel nxt = has_next ? G8Panel{(uint32_t)ntm * TA, (uint32_t)ntn * TB}
+                                 : G8Panel{cur.a + (uint32_t)(nkt - 2) * 128u, cur.b + (uint32_t)(nkt - 2) * 128u};
+    char* const here_c = g.C + ((size_t)tm * 256 * g.ldc + (size_t)tn * 256) * 2;
+    char* const here_z = ZOUT ? g.zout + ((size_t)tm * 256 * g.ldc + (size_t)tn * 256) * 2 : nullptr;
+    const uint32_t here_b = bias_ad0 + (uint32_t)parity * 1024u;
+
+#define G8P_ITER32(KIND, P1, P2, P3, PEND, FC, FZ, FB) \
+  g8p_iter32<T, ACT, BIAS, ZOUT, KIND>(g, A0e, A1e, B0e, B1e, A0o, A1o, B0o, B1o, ra, rb, P1, P2, P3, HA, HB, oa, ob, wave_lds, xoff, woff, acc, f, PEND, \
+                                       FC, FZ, clane, FB)
+    {
+      if constexpr (BIAS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (VMC_LDS void*)(bias_lds + parity * 1024 + wn * 256), 4, bias_lane,
+                                                 (uint32_t)(tn * 256 + 64 * wn) * 4u, 0, 0);
+      const G8Panel p1 = {cur.a + 128u, cur.b + 128u}, p2 = {cur.a + 256u, cur.b + 256u}, p3 = {cur.a + 384u, cur.b + 384u};
+      G8P_ITER32(G8P_HEAD, p1, p2, p3, prev_c != nullptr, prev_c, prev_z, prev_b);
+    }
+    for (int t = 2; t + 2 < nkt; t += 2) {
+      const G8Panel p1 = {cur.a + (uint32_t)(t + 1) * 128u, cur.b + (uint32_t)(t + 1) * 128u};
+      const G8Panel p2 = {cur.a + (uint32_t)(t + 2) * 128u, cur.b + (uint32_t)(t + 2) * 128u};
+      const G8Panel p3 = {cur.a + (uint32_t)(t + 3) * 128u, cur.b + (uint32_t)(t + 3) * 128u};
+      G8P_ITER32(G8P_STEADY, p1, p2, p3, false, here_c, here_z, here_b);
+    }
+    {
+      const G8Panel p1 = {cur.a + (uint32_t)(nkt - 1) * 128u, cur.b + (uint32_t)(nkt - 1) * 128u};
+      const G8Panel p3 = {nxt.a + 128u, nxt.b + 128u};
+      G8P_ITER32(G8P_ROLL, p1, nxt, p3, false, here_c, here_z, here_b);
+    }
+#undef G8P_ITER32
+    prev_c = here_c; prev_z = here_z; prev_b = here_b;
+    if (!has_next) break;
+    parity ^= 1;
+    bid = nbid; tm = ntm; tn = ntn; cur = nxt;
+  }
+  g8p_fin_quadrant32<T, ACT, BIAS, ZOUT, 1, 0>(g, acc[1][0], prev_c, prev_z, clane, prev_b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+}
+
 template <typename T, int ACT>
 static int g8_launch(GemmArgs& g, hipStream_t stream) {
   auto kern = gemm8_kernel<T, ACT>;
@@ -589,6 +820,22 @@ static int g8_launch(GemmArgs& g, hipStream_t stream) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), 8 * G8_SLOT, stream, g);
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int ACT, bool BIAS, bool ZOUT>
+static int g8p32_launch(GemmArgs& g, hipStream_t stream) {
+  auto kern = gemm8p32_kernel<T, ACT, BIAS, ZOUT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT + 2048);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  g.tiles_m = g.M / 256;
+  g.tiles_n = g.N / 256;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), 8 * G8_SLOT + 2048, stream, g);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -626,6 +873,15 @@ static int g8_pick(GemmArgs& g, hipStream_t s) {
   // accesses count in vmcnt -> one-tile kernel
   if (g.variant != VMC_GEMM_ONE_TILE && g8p_eligible(g)) {
     const bool b = g.bias != nullptr, z = g.zout != nullptr;
+    static const bool env32 = getenv("VMC_GEMM_MFMA32") && atoi(getenv("VMC_GEMM_MFMA32")) != 0;      // builder A/B switch
+    if ((env32 || g.variant == VMC_GEMM_MFMA32) && !z) {
+      if constexpr (ACT == VMC_ACT_NONE) {
+        if (b) return g8p32_launch<T, ACT, true, false>(g, s);
+        return g8p32_launch<T, ACT, false, false>(g, s);
+      } else if constexpr (ACT == VMC_ACT_QUICKGELU) {
+        if (b) return g8p32_launch<T, ACT, true, false>(g, s);
+      }
+    }
     if constexpr (ACT == VMC_ACT_NONE) {
       if (b && !z) return g8p_launch<T, ACT, true, false>(g, s);
       if (!b && !z) return g8p_launch<T, ACT, false, false>(g, s);

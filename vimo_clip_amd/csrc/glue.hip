@@ -170,7 +170,6 @@ extern "C" int vmc_scale_by_device_scalar(const float* x, float* y, size_t n, co
 // One 256-thread workgroup per CU runs `iters` rounds of 64 dependent-free bf16 MFMAs on pseudo-random operands and stamps
 // s_memtime (shader cycles) and s_memrealtime (100 MHz) around them: cycles / ticks x 100 MHz = the clock the chip holds under
 // that load (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to `out` only; nothing else reads them.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 // mode 0: v_mfma_f32_16x16x32_bf16, mode 1: v_mfma_f32_32x32x16_bf16 (same FLOPs per cycle; which clock does the chip hold?)
 __global__ void __launch_bounds__(256) clock_probe32_kernel(unsigned long long* __restrict__ out, int iters) {
   const unsigned seed = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;

@@ -47,6 +47,17 @@ VMC_HD int swz_w8(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); 
 VMC_HD int lds_off_w8(int row, int chunk) { return row * 128 + ((chunk ^ swz_w8(row)) << 4); }
 VMC_HD void stage_src_w8(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w8(row); }
 
+// The same tile on v_mfma_f32_32x32x16 (lane l: A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31]; accumulator reg i of lane l is
+// D[row 8(i>>2) + 4(l>>5) + (i&3)][col l&31]).  Lane (x = lane&31, h = lane>>5), operands passed as mfma(W, X):
+//   X fragment (mh, mt, kk): slot A_mh, row 64*wm + 32*mt + x, logical chunk 2*kk + h      (mt = 0..1, kk = 0..3)
+//   W fragment (nh, kk):     slot B_nh, row 32*wn + g8_w_row32(x), logical chunk 2*kk + h
+//   acc[mh][nh][mt][i] = C[128*mh + 64*wm + 32*mt + x][128*nh + 32*wn + g8_c_col32(h, i)]
+// g8_w_row32 is chosen so that registers 0..7 / 8..15 of a lane are 8 consecutive output columns each and the two lane halves
+// interleave: one 16-byte store per register octet, 32 contiguous bytes per row and instruction.  With swz_x (A) and swz_w8 (B)
+// every 16-lane group of the ds_read_b128 touches 16 distinct 16-B slots (tests/host/test_tile_index.cpp).
+VMC_HD int g8_w_row32(int w) { return 16 * (w >> 4) + 8 * ((w >> 2) & 1) + 4 * ((w >> 3) & 1) + (w & 3); }
+VMC_HD int g8_c_col32(int h, int i) { return 16 * (i >> 3) + 8 * h + (i & 7); }
+
 // Staging: 16-B chunk `idx` (LDS order) of an operand tile -> (row, logical chunk) to fetch.
 VMC_HD void stage_src_x(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_x(row); }
 VMC_HD void stage_src_w(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w(row); }
