@@ -297,6 +297,79 @@ static void test_gemm8_mfma32() {
   }
 }
 
+// TN weight gradient on the 256 x 256 tile: one 64-token stage = 4 half-tile slots (dY cols 0..127 / 128..255, X cols 0..127 / 128..255)
+static void test_tn256() {
+  std::vector<e16> dY(64 * 256), X(64 * 256);      // [token][column]
+  for (auto& x : dY) x = (e16)(rand() % 7 - 3);
+  for (auto& x : X) x = (e16)(rand() % 7 - 3);
+  std::vector<uint8_t> slot[4];  // A0 A1 B0 B1
+  for (auto& s : slot) s.assign(16384, 0xEE);
+  for (int tid = 0; tid < 512; ++tid)
+    for (int i = 0; i < 2; ++i) {
+      int row, ch;
+      tn_stage_src(i * 512 + tid, row, ch);
+      for (int h = 0; h < 2; ++h) {
+        memcpy(&slot[h][(size_t)(i * 512 + tid) * 16], &dY[row * 256 + 128 * h + ch * 8], 16);
+        memcpy(&slot[2 + h][(size_t)(i * 512 + tid) * 16], &X[row * 256 + 128 * h + ch * 8], 16);
+      }
+    }
+  for (int wave = 0; wave < 8; ++wave) {
+    const int wm = wave >> 2, wn = wave & 3;
+    for (int mh = 0; mh < 2; ++mh) for (int nh = 0; nh < 2; ++nh)
+      for (int mt = 0; mt < 4; ++mt) for (int nt = 0; nt < 2; ++nt) {
+        long acc[64][4]; memset(acc, 0, sizeof acc);
+        for (int kk = 0; kk < 2; ++kk) {
+          Frag af[64], bf[64];
+          for (int e = 0; e < 2; ++e) {
+            int aaddr[64], baddr[64];
+            for (int l = 0; l < 64; ++l) {
+              aaddr[l] = (tn256_a_off(wm, l, e) ^ (mt << 5)) + 8192 * kk;
+              baddr[l] = (tn256_b_off(wn, l, e) ^ (nt << 5)) + 8192 * kk;
+            }
+            CHECK(tr_conflict(aaddr) == 1, "tn256 A read conflict %d", tr_conflict(aaddr));
+            CHECK(tr_conflict(baddr) == 1, "tn256 B read conflict %d", tr_conflict(baddr));
+            e16 oa[64][4], ob[64][4];
+            tr_read(slot[mh], aaddr, oa);
+            tr_read(slot[2 + nh], baddr, ob);
+            for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) { af[l].v[4 * e + j] = oa[l][j]; bf[l].v[4 * e + j] = ob[l][j]; }
+          }
+          mfma16(bf, af, acc);       // (X, dY)
+        }
+        for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
+          const int r = l & 15, g = l >> 4;
+          const int n = 128 * mh + 64 * wm + 16 * mt + r, k = 128 * nh + 32 * wn + 16 * nt + 4 * g + j;
+          long ref = 0;
+          for (int t = 0; t < 64; ++t) ref += (long)dY[t * 256 + n] * X[t * 256 + k];
+          CHECK(acc[l][j] == ref, "tn256 wave %d mh %d nh %d mt %d nt %d lane %d j %d: %ld vs %ld", wave, mh, nh, mt, nt, l, j, acc[l][j], ref);
+        }
+      }
+    // bias gradient: pattern operand on the X side (ones iff (lane & 15) >> 2 == mt); lane (r, g) ends with the sum of column 64 wm + 16 g + r
+    if (wn == 0)
+      for (int mh = 0; mh < 2; ++mh) {
+        long acc[64][4]; memset(acc, 0, sizeof acc);
+        for (int mt = 0; mt < 4; ++mt)
+          for (int kk = 0; kk < 2; ++kk) {
+            Frag af[64], pf[64];
+            for (int e = 0; e < 2; ++e) {
+              int aaddr[64];
+              for (int l = 0; l < 64; ++l) aaddr[l] = (tn256_a_off(wm, l, e) ^ (mt << 5)) + 8192 * kk;
+              e16 oa[64][4];
+              tr_read(slot[mh], aaddr, oa);
+              for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) af[l].v[4 * e + j] = oa[l][j];
+            }
+            for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) pf[l].v[j] = (e16)((((l & 15) >> 2) == mt) ? 1 : 0);
+            mfma16(pf, af, acc);
+          }
+        for (int l = 0; l < 64; ++l) {
+          const int r = l & 15, g = l >> 4, n = 128 * mh + 64 * wm + 16 * g + r;
+          long ref = 0;
+          for (int t = 0; t < 64; ++t) ref += dY[t * 256 + n];
+          CHECK(acc[l][0] == ref, "tn256 bias wave %d mh %d lane %d: %ld vs %ld", wave, mh, l, acc[l][0], ref);
+        }
+      }
+  }
+}
+
 static void test_xcd_remap() {
   for (int nwg : {1, 7, 8, 9, 63, 64, 100, 1028, 3084}) {
     std::set<int> seen;
@@ -312,6 +385,7 @@ int main() {
   test_gemm(2, 2, 1);
   test_gemm8();
   test_gemm8_mfma32();
+  test_tn256();
   test_attention(18, 257);
   test_attention(4, 50);
   test_attention(2, 17);

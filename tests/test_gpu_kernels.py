@@ -334,7 +334,8 @@ def test_transpose_colsum_cast_pool_pe(ops):
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
-@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 768, 2048), (130, 64, 40), (4096, 512, 2048), (65536, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 768, 2048), (130, 64, 40), (4096, 512, 2048), (65536, 512, 512),
+                                   (25600, 3072, 768), (25600, 2304, 768), (6400, 1000, 2056), (256, 1024, 1024)])   # the last four: 256 x 256 tile (gemm_tn256.hip), ragged N / K, one stage pair
 def test_wgrad_tn_exact_integers(ops, dtype, M, N, K):
     # dW = dY^T X straight from token-major operands (ds_read_b64_tr_b16 fragments, split over the token range)
     dy = _ints((M, N), -2, 2, 31)
@@ -360,7 +361,7 @@ def test_linear_wgrad_splitk_exact_integers(ops, M, N, K):
     assert torch.equal(again, out)
 
 
-@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (1000, 2304, 768), (77, 144, 3072), (8192, 512, 2048), (25600, 3072, 768), (6400, 1000, 2056)])
 def test_wgrad_tn_with_bias_gradient(ops, M, N, K):
     # the same launch also returns db = column sums of dY (ones-MFMA on the fragments already in registers)
     dy = _ints((M, N), -2, 2, 51)

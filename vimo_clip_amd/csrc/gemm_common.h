@@ -80,3 +80,9 @@ __device__ __forceinline__ bool gemm_vec8_ok(const GemmArgs& g) {
 
 // 8-phase 256x256 kernel family (gemm8.hip); returns VMC_E_SHAPE when the shape does not qualify.
 int vmc_gemm8_launch(GemmArgs& g, int act, int dtype16, hipStream_t stream);
+
+// 256 x 256 TN weight-gradient kernel (gemm_tn256.hip), routed by gemm_tn.hip
+bool vmc_tn256_eligible(int M, int N, int K, int lddy, int ldx);
+void vmc_tn256_slices(int M, int N, int K, int* slices, int* pairs_per_slice);
+int vmc_tn256_launch(const void* dY, const void* X, float* dst, float* bdst, int M, int N, int K, int lddy, int ldx, int slices,
+                     int pairs_per_slice, int dtype16, hipStream_t s);

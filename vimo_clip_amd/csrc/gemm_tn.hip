@@ -82,8 +82,18 @@ static int tn_slices(int M, int N, int K) {
   const int per = (steps + slices - 1) / slices;
   return (steps + per - 1) / per;                      // no empty trailing slice
 }
+// Large problems made of whole 128-token pairs go to the 256 x 256 tile (gemm_tn256.hip); VMC_TN256=0 is the builder's A/B switch.
+static bool tn_use256(int M, int N, int K, int lddy, int ldx) {
+  static const bool on = !(getenv("VMC_TN256") && atoi(getenv("VMC_TN256")) == 0);
+  return on && vmc_tn256_eligible(M, N, K, lddy, ldx);
+}
 extern "C" size_t vmc_linear_wgrad_tn_workspace_bytes(int M, int N, int K) {
-  const int s = tn_slices(M, N, K);
+  int s = tn_slices(M, N, K);
+  if (vmc_tn256_eligible(M, N, K, N, K)) {     // the leading dimensions are not known here: room for whichever kernel the call takes
+    int s2, per;
+    vmc_tn256_slices(M, N, K, &s2, &per);
+    if (s2 > s) s = s2;
+  }
   return s > 1 ? (size_t)s * ((size_t)N * K + N) * sizeof(float) : 0;      // weight slabs, then bias slabs
 }
 extern "C" int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx,
@@ -92,13 +102,26 @@ extern "C" int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C,
   if ((N % 8) || (K % 8)) return VMC_E_SHAPE;
   if ((lddy % 8) || (ldx % 8)) return VMC_E_ALIGN;
   if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)C | (uintptr_t)workspace | (uintptr_t)dbias) & 15) return VMC_E_ALIGN;
-  const int slices = tn_slices(M, N, K);
-  if (slices > 1 && (!workspace || workspace_bytes < vmc_linear_wgrad_tn_workspace_bytes(M, N, K))) return VMC_E_ARG;
+  const bool big = tn_use256(M, N, K, lddy, ldx);
+  int slices = tn_slices(M, N, K), pairs_per_slice = 0;
+  if (big) vmc_tn256_slices(M, N, K, &slices, &pairs_per_slice);
+  if (slices > 1 && (!workspace || workspace_bytes < (size_t)slices * ((size_t)N * K + N) * sizeof(float))) return VMC_E_ARG;
   float* dst = slices > 1 ? (float*)workspace : C;
   float* bdst = !dbias ? nullptr : (slices > 1 ? (float*)workspace + (size_t)slices * N * K : dbias);
+  hipStream_t s = (hipStream_t)stream;
+  if (big) {
+    const int rc = vmc_tn256_launch(dY, X, dst, bdst, M, N, K, lddy, ldx, slices, pairs_per_slice, dtype16, s);
+    if (rc) return rc;
+    if (slices > 1) {
+      const size_t n4 = (size_t)N * K / 4, n4b = dbias ? (size_t)N / 4 : 0;
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, s, (const float*)workspace, C, slices, n4,
+                         (const float*)bdst, dbias, n4b);
+      VMC_CHECK_LAUNCH();
+    }
+    return 0;
+  }
   const int tiles_k = (K + 127) / 128, tiles_n = (N + 255) / 256;
   dim3 grid(tiles_n * tiles_k * slices);
-  hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)TN_STAGES * TN_STAGE;
   static bool attr_set = false;
   if (!attr_set) {

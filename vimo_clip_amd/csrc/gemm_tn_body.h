@@ -3,7 +3,6 @@
 #pragma once
 #include "gemm_common.h"
 
-__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ uint32_t tn_lds_addr(const char* p) { return (uint32_t)(uintptr_t)(const VMC_LDS char*)p; }
 
 // inline asm for the reason given in gemm8.hip: hipcc would drain vmcnt(0) in front of C++ LDS reads while LDS-DMA

@@ -62,6 +62,25 @@ VMC_HD int g8_c_col32(int h, int i) { return 16 * (i >> 3) + 8 * h + (i & 7); }
 VMC_HD void stage_src_x(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_x(row); }
 VMC_HD void stage_src_w(int idx, int& row, int& chunk) { row = idx >> 3; chunk = (idx & 7) ^ swz_w(row); }
 
+// ---- TN weight gradient, 256 x 256 tile (gemm_tn256.hip) -----------------------------------------
+// Half-tile image: [64 tokens][128 columns] = 256-B rows of sixteen 16-B chunks; physical chunk slot = logical chunk ^ tn_swz(token row).
+// ds_read_b64_tr_b16 (lane i of 16-lane group G gets element i&3 of the 8-byte pieces addressed by lanes 16G + 4e + (i>>2), e = 0..3):
+// lane (r = lane&15, g = lane>>4), q = r>>2, p = r&3 addresses token row 8g + q + 4e (e = which half of the lane's 8 tokens), columns
+// 16*tile + 4p .. +3 of its wave's window, and receives tokens 8g + 4e + 0..3 of column 16*tile + r.  tile only flips chunk bits 1-2:
+// address(tile) = address(0) ^ (tile << 5); the second 32 tokens of a stage are +8192 bytes.
+//   A (dY) fragment (mh, mt, kk): slot A_mh, window = columns 64*wm + [0,64);  B (X) fragment (nh, nt, kk): slot B_nh, columns 32*wn + [0,32)
+//   acc[mh][nh][mt][nt][j] = C[128*mh + 64*wm + 16*mt + r][128*nh + 32*wn + 16*nt + 4*g + j]      (operands passed as mfma(X, dY))
+VMC_HD int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+VMC_HD void tn_stage_src(int idx, int& row, int& chunk) { row = idx >> 4; chunk = (idx & 15) ^ tn_swz(row); }
+VMC_HD int tn256_a_off(int wm, int lane, int e) {
+  const int r = lane & 15, g = lane >> 4, q = r >> 2, p = r & 3, row = 8 * g + q + 4 * e;
+  return row * 256 + (((8 * wm + (p >> 1)) ^ tn_swz(row)) << 4) + (p & 1) * 8;
+}
+VMC_HD int tn256_b_off(int wn, int lane, int e) {
+  const int r = lane & 15, g = lane >> 4, q = r >> 2, p = r & 3, row = 8 * g + q + 4 * e;
+  return row * 256 + (((4 * wn + (p >> 1)) ^ tn_swz(row)) << 4) + (p & 1) * 8;
+}
+
 // Bijective XCD-aware remap of a 1-D block id (blocks b and b+8 share an XCD; give each XCD a
 // contiguous range of tiles so neighbouring tiles share operand panels in that XCD's L2).
 VMC_HD int xcd_remap(int bid, int nwg) {
