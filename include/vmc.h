@@ -481,6 +481,15 @@ int vmc_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, co
  * stream BESIDE other kernels (FusedAdam.enable_backward_overlap: 2 per CU leaves the wave slots the backward's workgroups need). */
 int vmc_adam_step_dev_bg(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2,
                          float eps, float weight_decay, int decoupled_wd, int max_workgroups, void* stream);
+/* AdamW update AND refresh of the 16-bit compute copies in one pass over the masters (what `optimizer.step()` followed by
+ * vmc_cast_weights_multi does in two: TFAM/train_and_eval.py:96 in a captured step).  desc / n_desc / total_tiles: the records of
+ * vmc_cast_weights_multi, every `w` pointing into the flat parameter arena p_base; g_base / m_base / v_base are the parallel arenas
+ * (element i of a tensor at the same offset in all four).  ranges: DEVICE array of n_ranges records of 16 bytes
+ * {uint64 offset; int32 n; int32 block0} for the arena slices that have no compute copy (biases, LayerNorm parameters, ...), record i
+ * owning blocks [block0, block0 of i+1) of 1024 elements.  Same arithmetic as vmc_adam_step_dev, bit for bit. */
+int vmc_adam_cast_multi(const void* desc, int n_desc, int total_tiles, const void* ranges, int n_ranges, int total_range_blocks,
+                        float* p_base, const float* g_base, float* m_base, float* v_base, const float* hyper, float beta1, float beta2,
+                        float eps, float weight_decay, int decoupled_wd, int dtype16, void* stream);
 /* sum of squares of a flat f32 buffer, accumulated (+=) into out[0] (global grad norm). */
 int vmc_sumsq(const float* x, size_t n, float* out, void* stream);
 

@@ -608,6 +608,52 @@ def test_device_state_adam_and_tick_match_host_adam():
     assert ob.dev_state[2:10].tolist() != seeds                # every step draws new dropout seeds
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_fused_adam_and_copy_refresh_equals_the_two_kernel_step(dtype):
+    """vmc_adam_cast_multi (AdamW + refresh of both 16-bit copies from the registers, one pass over the masters) against
+    vmc_adam_step_dev + vmc_cast_weights_multi: masters, moments and every compute copy bit for bit over 4 steps -- matrices with
+    both / one / no cached copy, ragged and non-multiple-of-4 shapes, 1-D parameters."""
+    from vimo_clip_amd import autograd_ops as ag
+    from vimo_clip_amd.optim import FusedAdam, GradArena
+    shapes = [(192, 128), (100, 72), (130, 50), (33,), (64, 64), (7, 9), (256,), (96, 3, 4, 4)]
+
+    def build(fused):
+        ps = [torch.nn.Parameter(synth.normal(8, f"p{i}", sh).cuda()) for i, sh in enumerate(shapes)]
+        opt = FusedAdam(GradArena(ps), lr=3e-3, weight_decay=0.1, decoupled=True).enable_device_state(base_seed=7)
+        opt.FUSED_CAST = fused
+        copies = {}
+        for i, p in enumerate(ps):
+            if p.dim() < 2 or i == 4:
+                continue                                      # 1-D parameters and one matrix have no compute copy
+            if i == 2:
+                copies[i] = (ag.weights.get(p, dtype, transposed=False, pad_k=p.shape[1] % 64 != 0),)
+            elif p.dim() == 2:
+                copies[i] = (ag.weights.get(p, dtype, transposed=False, pad_k=p.shape[1] % 64 != 0, both=True),
+                             ag.weights.get(p, dtype, transposed=True, pad_k=p.shape[0] % 64 != 0, both=True))
+        return ps, opt, copies
+
+    ag.weights.clear()
+    (pa, oa, ca), (pb, ob, cb) = build(False), build(True)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = synth.normal(20 + step, f"g{i}", tuple(a.shape)).cuda()
+            a._vmc_grad.copy_(g)
+            b._vmc_grad.copy_(g)
+        for o in (oa, ob):
+            o.tick()
+            o.step()
+    assert getattr(ob, "_fused_plan", None) is not None and getattr(oa, "_fused_plan", None) is None
+    assert torch.equal(oa.arena.flat_param, ob.arena.flat_param) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v)
+    assert not torch.equal(oa.arena.flat_param, torch.zeros_like(oa.arena.flat_param))
+    for i in ca:
+        for x, y in zip(ca[i], cb[i]):
+            assert torch.equal(x, y), i
+        w = ca[i][0]
+        ref = pa[i].detach().to(dtype)
+        assert torch.equal(w[:, :pa[i].shape[1]], ref)        # the copies are the rounded masters
+    ag.weights.clear()
+
+
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_captured_train_steps_equal_eager_device_state_steps(p_drop):
     """hipGraph-captured TFAM training steps (tick + fwd + bwd + AdamW): five replays follow the same trajectory as five eager

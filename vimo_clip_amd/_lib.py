@@ -92,6 +92,7 @@ SIGNATURES = {
     "vmc_train_tick": (I, [P, P, F, F, I, P]),
     "vmc_adam_step_dev": (I, [P, P, P, P, Z, P, F, F, F, F, I, P]),
     "vmc_adam_step_dev_bg": (I, [P, P, P, P, Z, P, F, F, F, F, I, I, P]),
+    "vmc_adam_cast_multi": (I, [P, I, I, P, I, I, P, P, P, P, P, F, F, F, F, I, I, P]),
     "vmc_sumsq": (I, [P, Z, P, P]),
 }
 

@@ -65,6 +65,13 @@ class _WeightCache:
         them one launch per parameter in the next forward.  Buffers keep their addresses (what a captured step needs).
         param_ids: ids of the parameters that were updated (an optimiser's arena); None = every cached trained parameter.
         owner: key under which the descriptor table of that parameter set is kept (the optimiser)."""
+        for dtype16, tab in self.tables(owner, param_ids).items():
+            check(lib.vmc_cast_weights_multi(ptr(tab[1]), tab[2], tab[3], dt(dtype16), stream()), "cast_weights_multi")
+        self.epoch += 1
+
+    def tables(self, owner=None, param_ids=None):
+        """dtype16 -> (key, device descriptor table, n, tiles, ids of the parameters it covers): the records vmc_cast_weights_multi and
+        vmc_adam_cast_multi take for every cached copy of the trained parameters in `param_ids` (stale copies are dropped)."""
         import numpy as np
         groups = {}                                   # dtype16 -> {id(p): [p, w16, w16t]}
         for (pid, dtype16, transposed, _pad), hit in list(self._c.items()):
@@ -80,6 +87,7 @@ class _WeightCache:
                 continue
             slot = groups.setdefault(dtype16, {}).setdefault(pid, [p, None, None])
             slot[2 if transposed else 1] = hit[3]
+        out = {}
         for dtype16, params in groups.items():
             key = (dtype16, tuple((pid, 0 if w is None else w.data_ptr(), 0 if wt is None else wt.data_ptr(), p.data_ptr())
                                   for pid, (p, w, wt) in params.items()))
@@ -102,11 +110,11 @@ class _WeightCache:
                     rec[i, 5] = tile0 | (tx << 32)
                     tile0 += tx * ty
                 dev = next(iter(params.values()))[0].device
-                tab = (key, torch.from_numpy(rec).to(dev), len(params), tile0)
+                tab = (key, torch.from_numpy(rec).to(dev), len(params), tile0, frozenset(params.keys()))
                 self._tables[(owner, dtype16)] = tab
                 self._old_tables.append(tab[1])       # a captured graph may still read an older table
-            check(lib.vmc_cast_weights_multi(ptr(tab[1]), tab[2], tab[3], dt(dtype16), stream()), "cast_weights_multi")
-        self.epoch += 1
+            out[dtype16] = tab
+        return out
 
 
 weights = _WeightCache()

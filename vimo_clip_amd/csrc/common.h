@@ -135,6 +135,18 @@ __device__ inline float dropout_factor(float p, uint64_t seed, uint64_t i) {
   return hash32(seed, i) >= (uint32_t)((double)p * 4294967296.0) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// One Adam / AdamW element update (torch.optim.Adam / AdamW, no amsgrad): every optimiser kernel goes through this expression, so
+// the flat kernel and the tile kernel that also refreshes the 16-bit copies agree bit for bit.
+__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float wd,
+                                             int decoupled, float step_size, float inv_sqrt_bc2, float gscale) {
+#pragma clang fp contract(off)      // which products fuse into FMAs must not depend on the kernel this is inlined into
+  float gr = g * gscale;
+  if (decoupled) p *= (1.0f - lr * wd); else gr += wd * p;
+  m = b1 * m + (1.0f - b1) * gr;
+  v = b2 * v + (1.0f - b2) * gr * gr;
+  p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+
 static inline int grid_for(size_t n, int block, int max_blocks = 256 * 16) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)max_blocks) g = max_blocks;

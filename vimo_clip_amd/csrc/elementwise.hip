@@ -441,6 +441,151 @@ __global__ void __launch_bounds__(256) cast_weights_multi_kernel(const CastDesc*
   }
 }
 
+// ---- AdamW update + refresh of the 16-bit copies in ONE pass over the masters (captured training steps) -----------------------
+// The optimiser step followed by vmc_cast_weights_multi reads every matrix twice (28 B per parameter for the update, 4 + 4 for
+// the copies); here a 64 x 64 tile of a matrix is updated in registers (adam_element: the expression of adam_kernel, same
+// bits) and leaves as p, m, v AND both 16-bit copies -- 28 + 4 B per parameter, one launch less.  The descriptors are those of
+// vmc_cast_weights_multi (w points into the flat parameter arena p_base; g / m / v are the parallel arenas); parameters without
+// compute copies (biases, LayerNorm, ...) are covered by `ranges`.
+template <typename T>
+__global__ void __launch_bounds__(256) adam_cast_multi_kernel(const CastDesc* __restrict__ desc, int n, const float* p_base,
+                                                              const float* __restrict__ g_base, float* __restrict__ m_base,
+                                                              float* __restrict__ v_base, const float* __restrict__ hyper, float b1, float b2,
+                                                              float eps, float wd, int decoupled) {
+  __shared__ uint16_t tile[64][68];
+  const float lr = hyper[0], step_size = hyper[1], inv_sqrt_bc2 = hyper[2], gscale = hyper[3];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int t = blockIdx.x - d.tile0;
+  const int r0 = (t / d.tiles_x) * 64, c0 = (t % d.tiles_x) * 64;
+  float* const w = const_cast<float*>(d.w);
+  const size_t base = (size_t)(d.w - p_base);
+  const float* const g = g_base + base;
+  float* const m = m_base + base;
+  float* const v = v_base + base;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool vec = (d.cols & 3) == 0 && (d.rows & 3) == 0 && (!d.w16 || ((d.ld & 3) == 0 && ((uintptr_t)d.w16 & 7) == 0)) &&
+                   (!d.w16t || ((d.ldt & 3) == 0 && ((uintptr_t)d.w16t & 7) == 0));       // arena slots are 256-byte aligned
+  if (vec) {
+    float4 pp[4], gg[4], mm[4], vv[4];
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // all loads of the tile first: 16 float4 in flight per thread
+      const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+      in[i] = r < d.rows && c < d.cols;
+      if (in[i]) {
+        const size_t e = (size_t)r * d.cols + c;
+        pp[i] = *(const float4*)(w + e); gg[i] = *(const float4*)(g + e); mm[i] = *(const float4*)(m + e); vv[i] = *(const float4*)(v + e);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+      uint2 pk = make_uint2(0u, 0u);
+      if (in[i]) {
+        float* P = &pp[i].x; const float* G = &gg[i].x; float* M = &mm[i].x; float* V = &vv[i].x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) adam_element(P[j], G[j], M[j], V[j], lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, gscale);
+        const size_t e = (size_t)r * d.cols + c;
+        *(float4*)(w + e) = pp[i]; *(float4*)(m + e) = mm[i]; *(float4*)(v + e) = vv[i];
+        pk = make_uint2((uint32_t)T::from_f32(P[0]) | ((uint32_t)T::from_f32(P[1]) << 16), (uint32_t)T::from_f32(P[2]) | ((uint32_t)T::from_f32(P[3]) << 16));
+        if (d.w16) *(uint2*)(d.w16 + (size_t)r * d.ld + c) = pk;
+      }
+      *(uint2*)&tile[ty + 16 * i][4 * tx] = pk;
+    }
+    if (!d.w16t) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 16 * i, r = r0 + 4 * tx;
+      if (c < d.cols && r < d.rows) {
+        const int cl = ty + 16 * i;
+        *(uint2*)(d.w16t + (size_t)c * d.ldt + r) = make_uint2((uint32_t)tile[4 * tx][cl] | ((uint32_t)tile[4 * tx + 1][cl] << 16),
+                                                              (uint32_t)tile[4 * tx + 2][cl] | ((uint32_t)tile[4 * tx + 3][cl] << 16));
+      }
+    }
+    return;
+  }
+  const int sx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  for (int i = sy; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + sx;
+    uint16_t h = 0;
+    if (r < d.rows && c < d.cols) {
+      const size_t e = (size_t)r * d.cols + c;
+      float pk = w[e], mk = m[e], vk = v[e];
+      adam_element(pk, g[e], mk, vk, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, gscale);
+      w[e] = pk; m[e] = mk; v[e] = vk;
+      h = T::from_f32(pk);
+      if (d.w16) d.w16[(size_t)r * d.ld + c] = h;
+    }
+    tile[i][sx] = h;
+  }
+  if (!d.w16t) return;
+  __syncthreads();
+  for (int i = sy; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + sx;
+    if (c < d.cols && r < d.rows) d.w16t[(size_t)c * d.ldt + r] = tile[sx][i];
+  }
+}
+
+// the parameters without compute copies: ranges[i] = {offset into the arenas, elements, first block}; 1024 elements per block
+struct AdamRange {
+  unsigned long long off;
+  int n, block0;
+};
+static_assert(sizeof(AdamRange) == 16, "vmc_adam_cast_multi range layout (include/vmc.h)");
+__global__ void __launch_bounds__(256) adam_ranges_kernel(const AdamRange* __restrict__ rr, int n, float* __restrict__ p_base,
+                                                          const float* __restrict__ g_base, float* __restrict__ m_base,
+                                                          float* __restrict__ v_base, const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                          float wd, int decoupled) {
+  const float lr = hyper[0], step_size = hyper[1], inv_sqrt_bc2 = hyper[2], gscale = hyper[3];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (rr[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamRange r = rr[lo];
+  const int i0 = ((int)blockIdx.x - r.block0) * 1024 + 4 * threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = i0 + j;
+    if (i < r.n) {
+      const size_t e = (size_t)r.off + i;
+      float pk = p_base[e], mk = m_base[e], vk = v_base[e];
+      adam_element(pk, g_base[e], mk, vk, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, gscale);
+      p_base[e] = pk; m_base[e] = mk; v_base[e] = vk;
+    }
+  }
+}
+
+extern "C" int vmc_adam_cast_multi(const void* desc, int n_desc, int total_tiles, const void* ranges, int n_ranges, int total_range_blocks,
+                                   float* p_base, const float* g_base, float* m_base, float* v_base, const float* hyper, float beta1,
+                                   float beta2, float eps, float weight_decay, int decoupled_wd, int dtype16, void* stream) {
+  if (!p_base || !g_base || !m_base || !v_base || !hyper) return VMC_E_ARG;
+  if ((n_desc > 0) != (desc != nullptr && total_tiles > 0) || (n_ranges > 0) != (ranges != nullptr && total_range_blocks > 0)) return VMC_E_ARG;
+  if (((uintptr_t)p_base | (uintptr_t)g_base | (uintptr_t)m_base | (uintptr_t)v_base | (uintptr_t)hyper) & 15) return VMC_E_ALIGN;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+  if (n_desc > 0) {
+    if (dtype16 == VMC_BF16)
+      hipLaunchKernelGGL(adam_cast_multi_kernel<BF16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)desc, n_desc, p_base,
+                         g_base, m_base, v_base, hyper, beta1, beta2, eps, weight_decay, decoupled_wd);
+    else
+      hipLaunchKernelGGL(adam_cast_multi_kernel<F16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const CastDesc*)desc, n_desc, p_base,
+                         g_base, m_base, v_base, hyper, beta1, beta2, eps, weight_decay, decoupled_wd);
+    VMC_CHECK_LAUNCH();
+  }
+  if (n_ranges > 0) {
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3(total_range_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamRange*)ranges, n_ranges, p_base,
+                       g_base, m_base, v_base, hyper, beta1, beta2, eps, weight_decay, decoupled_wd);
+    VMC_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 extern "C" int vmc_cast_weights_multi(const void* desc, int n_desc, int total_tiles, int dtype16, void* stream) {
   if (!desc || n_desc <= 0 || total_tiles <= 0) return VMC_E_ARG;
   if (dtype16 == VMC_BF16)

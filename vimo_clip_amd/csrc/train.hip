@@ -200,25 +200,16 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
       if (u == 1 && !two) break;
       float* P = &pp[u].x; const float* G = &gg[u].x; float* M = &mm[u].x; float* V = &vv[u].x;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float gr = G[j] * gscale;
-        if (decoupled) P[j] *= (1.0f - lr * wd); else gr += wd * P[j];
-        M[j] = b1 * M[j] + (1.0f - b1) * gr;
-        V[j] = b2 * V[j] + (1.0f - b2) * gr * gr;
-        P[j] -= step_size * M[j] / (sqrtf(V[j]) * inv_sqrt_bc2 + eps);
-      }
+      for (int j = 0; j < 4; ++j) adam_element(P[j], G[j], M[j], V[j], lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, gscale);
       const size_t i = u ? i1 : i0;
       ((float4*)p)[i] = pp[u]; ((float4*)m)[i] = mm[u]; ((float4*)v)[i] = vv[u];
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t k = (n4 << 2) + threadIdx.x;
-    float gr = g[k] * gscale, pk = p[k];
-    if (decoupled) pk *= (1.0f - lr * wd); else gr += wd * pk;
-    const float mk = b1 * m[k] + (1.0f - b1) * gr;
-    const float vk = b2 * v[k] + (1.0f - b2) * gr * gr;
-    p[k] = pk - step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
-    m[k] = mk; v[k] = vk;
+    float pk = p[k], mk = m[k], vk = v[k];
+    adam_element(pk, g[k], mk, vk, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, gscale);
+    p[k] = pk; m[k] = mk; v[k] = vk;
   }
 }
 

@@ -222,9 +222,51 @@ class FusedAdam:
         if max_grad_norm is not None:              # torch.nn.utils.clip_grad_norm_ (train.py:105-106)
             grad_scale = clipped_grad_scale(float(a.grad_norm().item()), grad_scale, max_grad_norm)
         self._open_step()
+        if dev_mode and self._fused_update():          # AdamW + refresh of the 16-bit copies in one pass over the masters
+            self._step_open = False
+            return
         self._update_range(0, a.numel, grad_scale)
         self._step_open = False
         invalidate_weight_copies(self)
+
+    FUSED_CAST = os.environ.get("VMC_ADAM_FUSED_CAST", "1") != "0"      # builder A/B switch
+
+    def _fused_update(self) -> bool:
+        """Device-state mode: vmc_adam_cast_multi updates every matrix tile by tile and writes its 16-bit compute copies from the
+        registers (one read of the masters instead of two), a second small launch covers the parameters without copies.  Needs all
+        cached copies of this arena's parameters in ONE compute dtype; otherwise the two-kernel path runs."""
+        if not self.FUSED_CAST:
+            return False
+        import numpy as np
+        from . import autograd_ops
+        from ._lib import dt
+        a = self.arena
+        ids = getattr(self, "_param_ids", None)
+        if ids is None:
+            ids = self._param_ids = frozenset(id(p) for p in a.params)
+        tabs = autograd_ops.weights.tables(owner=id(self), param_ids=ids)
+        if len(tabs) != 1:
+            return False
+        (dtype16, tab), = tabs.items()
+        covered = tab[4]
+        plan = getattr(self, "_fused_plan", None)
+        if plan is None or plan[0] != covered:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("optimiser plan changed while a graph is being captured: run one eager step first")
+            rest = [(o, p.numel()) for p, o in zip(a.params, a.offsets) if id(p) not in covered]
+            rec = np.zeros((max(1, len(rest)), 2), dtype=np.int64)
+            block0 = 0
+            for i, (o, n) in enumerate(rest):
+                rec[i, 0] = o
+                rec[i, 1] = n | (block0 << 32)
+                block0 += (n + 1023) // 1024
+            plan = self._fused_plan = (covered, torch.from_numpy(rec).to(a.flat_param.device), len(rest), block0)
+            self._old_plans = getattr(self, "_old_plans", []) + [plan[1]]      # a captured graph may still read an older table
+        check(lib.vmc_adam_cast_multi(ptr(tab[1]), tab[2], tab[3], ptr(plan[1]) if plan[2] else None, plan[2], plan[3], ptr(a.flat_param),
+                                      ptr(a.flat_grad), ptr(self.m), ptr(self.v), ptr(self.dev_hyper), float(self.betas[0]), float(self.betas[1]),
+                                      float(self.eps), float(self.weight_decay), int(self.decoupled), dt(dtype16), stream()), "adam_cast_multi")
+        autograd_ops.weights.epoch += 1
+        return True
 
     def state_dict(self):
         return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
