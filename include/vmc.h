@@ -132,6 +132,20 @@ int vmc_linear_wgrad_tn(const void* dY, const void* X, float* C, int M, int N, i
 int vmc_linear_wgrad_bias_tn(const void* dY, const void* X, float* C, float* dbias, int M, int N, int K, int lddy, int ldx,
                              void* workspace, size_t workspace_bytes, int dtype16, void* stream);
 
+/* Many TN weight gradients in ONE launch (the weight gradients of a training step: TFAM/train_and_eval.py:94-95, train.py:103-104 --
+ * `loss.backward()` leaves one small dW = dY^T X per linear).  Every 256 x 256 tile runs over all M tokens of its problem: no token
+ * slices, no workspace, no reduce launch.  Per problem: M % 128 == 0 and M >= 256, N % 8 == 0, K % 8 == 0, lddy / ldx % 8 == 0,
+ * operands < 2 GiB, pointers 16-byte aligned; C [N, K] f32 contiguous, dbias [N] f32 or NULL (column sums of dY).  n <= VMC_WGRAD_GROUP_MAX. */
+#define VMC_WGRAD_GROUP_MAX 32
+typedef struct vmc_wgrad_tn_problem {
+  const void* dY;      /* [M, lddy] 16-bit */
+  const void* X;       /* [M, ldx] 16-bit */
+  float* C;            /* [N, K] */
+  float* dbias;        /* [N] or NULL */
+  int M, N, K, lddy, ldx, reserved;
+} vmc_wgrad_tn_problem;
+int vmc_linear_wgrad_tn_group(const vmc_wgrad_tn_problem* probs, int n, int dtype16, void* stream);
+
 /* vmc_linear with the large-problem kernel chosen PER CALL (A/B measurements in one process; the library keeps no
  * state): VMC_GEMM_TWOSTAGE = two-stage tiles only, VMC_GEMM_DEFAULT = what vmc_linear does (8-phase 256x256 kernel; the
  * tile rows of a small last partial round handed to the small-tile kernel in a second launch; whole-tile problems with a

@@ -373,6 +373,40 @@ def test_wgrad_tn_with_bias_gradient(ops, M, N, K):
     assert torch.equal(db.cpu(), dy.sum(0))
 
 
+@pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
+def test_wgrad_tn_group_exact_integers(ops, dtype):
+    """vmc_linear_wgrad_tn_group: several weight gradients (and their bias gradients) from one launch, every tile over all tokens of its
+    problem -- different M, ragged N / K, strided operands (a column window of a wider tensor), with and without bias gradient."""
+    shapes = [(8192, 768, 768, True), (8192, 2304, 768, True), (1024, 1000, 2056, False), (256, 64, 40, True), (4096, 768, 2048, True),
+              (8192, 768, 768, False), (2560, 520, 264, True)]
+    probs, refs = [], []
+    for i, (M, N, K, with_b) in enumerate(shapes):
+        dy = _ints((M, N), -2, 2, 71 + i)
+        x = _ints((M, K), -3, 3, 91 + i)
+        dy[:, 1] += (torch.arange(M) % 3).float()
+        x[:, 2] += (torch.arange(M) % 2).float()
+        ref = dy.t() @ x
+        assert ref.abs().max() < 2 ** 24
+        if i == 1:                                     # dY as a column window of a wider row-major tensor (lddy > N)
+            wide = torch.zeros(M, N + 512)
+            wide[:, 256:256 + N] = dy
+            dyd = wide.to(DEV, dtype)[:, 256:256 + N]
+        else:
+            dyd = dy.to(DEV, dtype)
+        out = torch.full((N, K), 7.0, device=DEV)
+        db = torch.full((N,), 5.0, device=DEV) if with_b else None
+        assert ops.wgrad_group_ok(dyd, x.to(DEV, dtype), out)
+        probs.append((dyd, x.to(DEV, dtype), out, db))
+        refs.append((ref, dy.sum(0) if with_b else None))
+    ops.wgrad_tn_group(probs, dtype)
+    for (dyd, xd, out, db), (ref, rb) in zip(probs, refs):
+        assert torch.equal(out.cpu(), ref), f"max diff {(out.cpu() - ref).abs().max()}"
+        if rb is not None:
+            assert torch.equal(db.cpu(), rb)
+    assert not ops.wgrad_group_ok(torch.zeros(200, 64, device=DEV, dtype=dtype), torch.zeros(200, 64, device=DEV, dtype=dtype),
+                                  torch.zeros(64, 64, device=DEV))        # M not a multiple of 128: the sliced kernel's case
+
+
 @pytest.mark.parametrize("M,N,K,act", [(65792, 1024, 128, 1), (25600, 768, 256, 2), (300, 96, 64, 1), (4096, 512, 128, 3), (777, 264, 192, 1)])
 def test_linear_preact_side_output(ops, M, N, K, act):
     # vmc_linear_preact: C = act(A W^T + b) and Z = A W^T + b from one epilogue (8-phase interior tiles, its 256-row tail,

@@ -608,6 +608,60 @@ def test_device_state_adam_and_tick_match_host_adam():
     assert ob.dev_state[2:10].tolist() != seeds                # every step draws new dropout seeds
 
 
+def test_grouped_weight_gradients_equal_the_per_linear_launches():
+    """autograd_ops.wgrad_queue: the weight gradients of a backward pass parked and launched as groups (vmc_linear_wgrad_tn_group,
+    every tile over all tokens) against one sliced launch + reduce per linear -- same arena, every parameter; also with a
+    gradient-ready hook registered (small groups during the backward; each parameter reported as often as without grouping)."""
+    from vimo_clip_amd import autograd_ops as ag
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import GradArena
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    B, T, D = 64, 16, 768
+    m = AMO_CLIP(d_model=D, nhead=8, num_layers=2, dim_feedforward=2048, num_classes=140, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda().train()
+    m.load_state_dict(synth.tfam_state_dict(D, 8, 2, 2048, 140, 5), strict=True)
+    arena = GradArena(m.used_parameters())
+    rgb, mot = synth.normal(41, "rgb", (B, T, D)).cuda(), synth.normal(41, "mot", (B, T, D)).cuda()
+    mk = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    y = synth.multi_hot_labels(41, "lab", B, 140).cuda()
+    grads, reports = {}, {}
+    was = ag.wgrad_queue.enabled
+    try:
+        for mode in ("single", "grouped", "grouped+hook"):
+            ag.wgrad_queue.enabled = mode != "single"
+            seen = {}
+            hook = lambda p: seen.__setitem__(id(p), seen.get(id(p), 0) + 1)      # noqa: E731
+            if mode != "single":
+                ag.grad_ready_hooks.append(hook)
+            if mode == "grouped":
+                ag.grad_ready_hooks.remove(hook)
+            arena.flat_grad.fill_(123.0)
+            bce_with_logits_loss(m(rgb, mot, mask_rgb=mk, mask_flow=mk), y).backward()
+            assert not ag.wgrad_queue.items                     # flushed by the end-of-backward callback
+            torch.cuda.synchronize()
+            grads[mode] = arena.flat_grad.clone()
+            reports[mode] = seen
+            if hook in ag.grad_ready_hooks:
+                ag.grad_ready_hooks.remove(hook)
+    finally:
+        ag.wgrad_queue.enabled = was
+    ref = grads["single"]
+    assert not (ref == 123.0).all()
+    for mode in ("grouped", "grouped+hook"):
+        for p, o in zip(arena.params, arena.offsets):
+            a, b = ref[o:o + p.numel()], grads[mode][o:o + p.numel()]
+            assert (a - b).abs().max().item() <= 2e-4 * max(1e-6, a.abs().max().item()), (mode, tuple(p.shape))
+    ag.wgrad_queue.enabled = False
+    seen = {}
+    hook = lambda p: seen.__setitem__(id(p), seen.get(id(p), 0) + 1)              # noqa: E731
+    ag.grad_ready_hooks.append(hook)
+    try:
+        bce_with_logits_loss(m(rgb, mot, mask_rgb=mk, mask_flow=mk), y).backward()
+    finally:
+        ag.grad_ready_hooks.remove(hook)
+        ag.wgrad_queue.enabled = was
+    assert seen == reports["grouped+hook"]                      # the reducer's per-parameter report counts are unchanged
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_fused_adam_and_copy_refresh_equals_the_two_kernel_step(dtype):
     """vmc_adam_cast_multi (AdamW + refresh of both 16-bit copies from the registers, one pass over the masters) against

@@ -36,6 +36,7 @@ SIGNATURES = {
     "vmc_linear_wgrad_tn_workspace_bytes": (Z, [I, I, I]),
     "vmc_linear_wgrad_tn": (I, [P, P, P, I, I, I, I, I, P, Z, I, P]),
     "vmc_linear_wgrad_bias_tn": (I, [P, P, P, P, I, I, I, I, I, P, Z, I, P]),
+    "vmc_linear_wgrad_tn_group": (I, [P, I, I, P]),
     "vmc_linear_variant": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, I, I, I, I, P]),
     "vmc_transpose16": (I, [P, P, I, I, I, I, P]),
     "vmc_cast_weight": (I, [P, P, P, I, I, I, I, I, P]),

@@ -12,6 +12,7 @@ function says otherwise; parameters are fp32 masters whose 16-bit copies are cac
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -141,6 +142,60 @@ def _deliver(param, grad):
     return None
 
 
+class _WgradQueue:
+    """Weight gradients of one backward pass, batched.  A training step leaves one dW = dY^T X per linear, each too small to fill
+    the chip on its own (TFAM at B = 512: 9 .. 27 output tiles over 8192 tokens; launched alone it is cut into token slices plus a
+    reduce launch).  LinearFn.backward parks eligible problems here -- operands, the arena slots they write, the parameters whose
+    gradient-ready hooks must fire -- and they leave as grouped launches (ops.wgrad_tn_group: every tile over all tokens, no slabs):
+    when the queue is full, at the end of the backward pass (autograd engine callback) and, as a safety net, before the optimiser
+    or a gradient norm reads the arena.  With gradient-ready hooks registered (data-parallel bucket exchange) the groups are kept
+    small so that buckets still go out during the backward."""
+    enabled = os.environ.get("VMC_WGRAD_GROUP", "1") != "0"       # builder A/B switch
+    MAX_PROBLEMS = 28
+    MAX_PROBLEMS_WITH_HOOKS = 8
+    MAX_TILES = 1024
+
+    def __init__(self):
+        self.items = []
+        self.tiles = 0
+        self._cb = False
+
+    def push(self, dz, x, out, db, params):
+        self.items.append((dz, x, out, db, params))
+        self.tiles += ((dz.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256)
+        if not self._cb:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self._cb = True
+            except RuntimeError:                       # not inside an engine-driven backward pass: nothing will call back
+                self.flush()
+                return
+        if len(self.items) >= (self.MAX_PROBLEMS_WITH_HOOKS if grad_ready_hooks else self.MAX_PROBLEMS) or self.tiles >= self.MAX_TILES:
+            self.flush()
+
+    def _end_of_backward(self):
+        self._cb = False
+        self.flush()
+
+    def flush(self):
+        items, self.items, self.tiles = self.items, [], 0
+        if not items:
+            return
+        by_dtype = {}
+        for it in items:
+            by_dtype.setdefault(it[0].dtype, []).append(it)
+        for dtype16, group in by_dtype.items():
+            for i in range(0, len(group), ops.WGRAD_GROUP_MAX):
+                ops.wgrad_tn_group([(dz, x, out, db) for dz, x, out, db, _ in group[i:i + ops.WGRAD_GROUP_MAX]], dtype16)
+        for it in items:
+            for param in it[4]:
+                for hook in grad_ready_hooks:          # data-parallel reducer: the gradient is enqueued now
+                    hook(param)
+
+
+wgrad_queue = _WgradQueue()
+
+
 def _grad_out(param, shape):
     """Destination for a parameter gradient: the arena slot when present (written in place)."""
     slot = getattr(param, "_vmc_grad", None)
@@ -264,6 +319,15 @@ class LinearFn(torch.autograd.Function):
                     else:
                         db = db_view = _grad_out(bias, (N,))
                     db_done = True
+                dst = None
+                if Kx == K and slot is not None and slot.is_contiguous() and wgrad_queue.enabled:
+                    dst = slot.view(weight.shape[0], K)[lo:hi]
+                    bias_in_arena = db_view is None or getattr(bias, "_vmc_grad", None) is not None
+                    if not (bias_in_arena and ops.wgrad_group_ok(dz, x, dst) and (db_view is None or db_view.data_ptr() % 16 == 0)):
+                        dst = None
+                if dst is not None:                    # grouped with the other weight gradients of this backward pass
+                    wgrad_queue.push(dz, x, dst, db_view, [weight] + ([bias] if db_view is not None else []))
+                    return dx, None, None, dres, None, None, None, None
                 if Kx == K:
                     if rows is not None:
                         if slot is not None:

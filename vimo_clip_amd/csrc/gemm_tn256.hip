@@ -129,23 +129,17 @@ __device__ __forceinline__ void t2_coords(int bid, int tiles_n, int tiles_k, int
   }
 }
 
+// One 256 x 256 output tile (tn, tk) over the 64-token stages [s0, s0 + nkt) (nkt even, >= 2); partial result to slab `slice`.
 template <typename T>
-__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ C,
-                                                            float* __restrict__ dbias, int M, int N, int K, int lddy, int ldx, int tiles_k,
-                                                            int tiles_n, int slices, int pairs_per_slice) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tn256_tile_body(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ C,
+                                                float* __restrict__ dbias, int M, int N, int K, int lddy, int ldx, int tn, int tk, int s0,
+                                                int nkt, int slice, char* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 15, g = lane >> 4, q = r >> 2;
-
-  int tn, tk, slice;
-  t2_coords(blockIdx.x, tiles_n, tiles_k, slices, tn, tk, slice);
   const int n0 = tn * 256, k0 = tk * 256;
-  const int pairs_all = M >> 7;
-  const int p0 = slice * pairs_per_slice, p1 = min(pairs_all, p0 + pairs_per_slice);
-  const int s0 = 2 * p0, nkt = 2 * (p1 - p0);       // 64-token stages of this slice: even, >= 2 (host: no empty slice)
 
   // LDS-DMA: image chunk c = i * 512 + tid of a half-tile -> token row c >> 4, slot c & 15, source chunk = slot ^ swz(row)
   uint32_t oa[2], ob[2];
@@ -256,6 +250,54 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const uint16_t* __re
   }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ C,
+                                                            float* __restrict__ dbias, int M, int N, int K, int lddy, int ldx, int tiles_k,
+                                                            int tiles_n, int slices, int pairs_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tn, tk, slice;
+  t2_coords(blockIdx.x, tiles_n, tiles_k, slices, tn, tk, slice);
+  const int pairs_all = M >> 7;
+  const int p0 = slice * pairs_per_slice, p1 = min(pairs_all, p0 + pairs_per_slice);
+  tn256_tile_body<T>(dY, X, C, dbias, M, N, K, lddy, ldx, tn, tk, 2 * p0, 2 * (p1 - p0), slice, smem);     // no empty slice (host)
+}
+
+// ---- many weight gradients in ONE launch ------------------------------------------------------------------------------------------
+// A training step's weight gradients are many independent problems that are each too small to fill the chip (TFAM at B = 512:
+// 768 x 768 .. 2304 x 768 over 8192 tokens = 9 .. 27 tiles): launched one by one they are cut into up to 14 token slices whose
+// slabs a second launch reduces (28 + 7 us for 9.7 GFLOP).  Grouped, every tile runs over ALL tokens of its problem (no slabs, no
+// reduce, one launch), and the tiles of up to 32 problems fill the rounds.  Same tile body; block -> (problem, tile) through the
+// prefix table in the kernel argument; the XCD-aware order is applied to the whole grid.
+struct Tn256Group {
+  vmc_wgrad_tn_problem p[VMC_WGRAD_GROUP_MAX];
+  int tile0[VMC_WGRAD_GROUP_MAX + 1];     // first block of problem i; tile0[n] = grid size
+  int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(512, 2) gemm_tn256_group_kernel(const Tn256Group g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = xcd_remap(blockIdx.x, g.tile0[g.n]);
+  int i = 0;
+  while (i + 1 < g.n && g.tile0[i + 1] <= L) ++i;
+  const vmc_wgrad_tn_problem& pr = g.p[i];
+  const int tiles_k = (pr.K + 255) / 256, tiles_n = (pr.N + 255) / 256;
+  const int rest = L - g.tile0[i];
+  constexpr int KW = 8;                         // k tiles in chunks of 8, n tiles inside a chunk (t2_coords)
+  const int nfull = tiles_k / KW, full_sz = tiles_n * KW;
+  int tn, tk;
+  if (rest < nfull * full_sz) {
+    const int c = rest / full_sz, w = rest - c * full_sz;
+    tn = w / KW;
+    tk = c * KW + (w - tn * KW);
+  } else {
+    const int rem = rest - nfull * full_sz, wl = tiles_k - nfull * KW;
+    tn = rem / wl;
+    tk = nfull * KW + (rem - tn * wl);
+  }
+  tn256_tile_body<T>((const uint16_t*)pr.dY, (const uint16_t*)pr.X, pr.C, pr.dbias, pr.M, pr.N, pr.K, pr.lddy, pr.ldx, tn, tk, 0, pr.M >> 6, 0,
+                     smem);
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 // Eligibility and slicing are shared with gemm_tn.hip through these two functions (declared in gemm_common.h).
 bool vmc_tn256_eligible(int M, int N, int K, int lddy, int ldx) {
@@ -300,6 +342,40 @@ int vmc_tn256_launch(const void* dY, const void* X, float* dst, float* bdst, int
                        tiles_k, tiles_n, slices, pairs_per_slice);
   else
     return VMC_E_DTYPE;
+  VMC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vmc_linear_wgrad_tn_group(const vmc_wgrad_tn_problem* probs, int n, int dtype16, void* stream) {
+  if (!probs || n <= 0 || n > VMC_WGRAD_GROUP_MAX) return VMC_E_ARG;
+  if (dtype16 != VMC_BF16 && dtype16 != VMC_F16) return VMC_E_DTYPE;
+  Tn256Group g;
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const vmc_wgrad_tn_problem& p = probs[i];
+    if (!p.dY || !p.X || !p.C || p.M < 256 || p.N <= 0 || p.K <= 0) return VMC_E_ARG;
+    if ((p.M & 127) || (p.N % 8) || (p.K % 8)) return VMC_E_SHAPE;
+    if ((p.lddy % 8) || (p.ldx % 8) || p.lddy < p.N || p.ldx < p.K) return VMC_E_ALIGN;
+    if (((uintptr_t)p.dY | (uintptr_t)p.X | (uintptr_t)p.C | (uintptr_t)p.dbias) & 15) return VMC_E_ALIGN;
+    if ((size_t)p.M * p.lddy * 2 >= (1ull << 31) || (size_t)p.M * p.ldx * 2 >= (1ull << 31)) return VMC_E_SHAPE;      // buffer descriptors
+    g.p[i] = p;
+    g.tile0[i] = tiles;
+    tiles += ((p.N + 255) / 256) * ((p.K + 255) / 256);
+  }
+  g.tile0[n] = tiles;
+  const size_t lds = 8 * T2_SLOT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_group_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn256_group_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (dtype16 == VMC_BF16)
+    hipLaunchKernelGGL(gemm_tn256_group_kernel<BF16>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(gemm_tn256_group_kernel<F16>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, g);
   VMC_CHECK_LAUNCH();
   return 0;
 }

@@ -6,6 +6,8 @@ compute fallback.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -124,6 +126,36 @@ def wgrad_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor, dbias: torch.
     check(lib.vmc_linear_wgrad_bias_tn(ptr(dy), ptr(x), ptr(out), ptr(dbias), M, N, K, dy.stride(0), x.stride(0), ptr(ws), nbytes, dt(dy),
                                        stream()), "linear_wgrad_bias_tn")
     return out
+
+
+class WgradProblem(ctypes.Structure):          # vmc_wgrad_tn_problem (include/vmc.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("C", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("lddy", ctypes.c_int), ("ldx", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+WGRAD_GROUP_MAX = 32
+
+
+def wgrad_group_ok(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> bool:
+    """Shapes vmc_linear_wgrad_tn_group takes (whole 128-token pairs, 8-column granularity, < 2 GiB operands, contiguous f32 output)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    return (M >= 256 and M % 128 == 0 and N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+            and dy.stride(1) == 1 and x.stride(1) == 1 and out.is_contiguous() and out.dtype == torch.float32
+            and M * dy.stride(0) * 2 < (1 << 31) and M * x.stride(0) * 2 < (1 << 31)
+            and (dy.data_ptr() | x.data_ptr() | out.data_ptr()) % 16 == 0)
+
+
+def wgrad_tn_group(problems, dtype16) -> None:
+    """problems: list of (dy [M,N], x [M,K], out [N,K] f32, dbias [N] f32 or None), at most WGRAD_GROUP_MAX: every out = dy^T @ x and
+    dbias = column sums of dy from ONE launch (vmc_linear_wgrad_tn_group: no token slices, no workspace, no reduce)."""
+    n = len(problems)
+    arr = (WgradProblem * n)()
+    for i, (dy, x, out, db) in enumerate(problems):
+        arr[i] = WgradProblem(dy.data_ptr(), x.data_ptr(), out.data_ptr(), db.data_ptr() if db is not None else None,
+                              dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0), 0)
+    check(lib.vmc_linear_wgrad_tn_group(ctypes.cast(arr, ctypes.c_void_p), n, dt(dtype16), stream()), "linear_wgrad_tn_group")
 
 
 def layernorm(x: torch.Tensor, gamma, beta, dtype16, *, out16=True, out32=False, y32=None, rows=None, ldx=None,

@@ -49,6 +49,8 @@ class GradArena:
         self.flat_grad.zero_()
 
     def grad_norm(self) -> torch.Tensor:
+        from . import autograd_ops
+        autograd_ops.wgrad_queue.flush()
         out = torch.zeros(1, dtype=torch.float32, device=self.flat_grad.device)
         check(lib.vmc_sumsq(ptr(self.flat_grad), self.numel, ptr(out), stream()), "sumsq")
         return out.sqrt()
@@ -196,6 +198,8 @@ class FusedAdam:
         ov["done"][i] = ov["used"] = True
 
     def step(self, grad_scale: float = 1.0, max_grad_norm=None):
+        from . import autograd_ops
+        autograd_ops.wgrad_queue.flush()               # normally empty: the backward pass flushes its grouped weight gradients itself
         a = self.arena
         dev_mode = getattr(self, "dev_state", None) is not None
         ov = getattr(self, "_ov", None)
