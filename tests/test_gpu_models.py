@@ -611,7 +611,7 @@ def test_device_state_adam_and_tick_match_host_adam():
 def test_grouped_weight_gradients_equal_the_per_linear_launches():
     """autograd_ops.wgrad_queue: the weight gradients of a backward pass parked and launched as groups (vmc_linear_wgrad_tn_group,
     every tile over all tokens) against one sliced launch + reduce per linear -- same arena, every parameter; also with a
-    gradient-ready hook registered (small groups during the backward; each parameter reported as often as without grouping)."""
+    gradient-ready hook registered (each parameter reported as often as without grouping)."""
     from vimo_clip_amd import autograd_ops as ag
     from vimo_clip_amd.losses import bce_with_logits_loss
     from vimo_clip_amd.optim import GradArena

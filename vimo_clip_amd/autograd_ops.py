@@ -148,12 +148,12 @@ class _WgradQueue:
     reduce launch).  LinearFn.backward parks eligible problems here -- operands, the arena slots they write, the parameters whose
     gradient-ready hooks must fire -- and they leave as grouped launches (ops.wgrad_tn_group: every tile over all tokens, no slabs):
     when the queue is full, at the end of the backward pass (autograd engine callback) and, as a safety net, before the optimiser
-    or a gradient norm reads the arena.  With gradient-ready hooks registered (data-parallel bucket exchange) the groups are kept
-    small so that buckets still go out during the backward."""
+    or a gradient norm reads the arena.  With gradient-ready hooks registered in a job of more than one rank (data-parallel bucket
+    exchange) a group leaves as soon as it fills one round of the chip, so that buckets still go out during the backward."""
     enabled = os.environ.get("VMC_WGRAD_GROUP", "1") != "0"       # builder A/B switch
     MAX_PROBLEMS = 28
-    MAX_PROBLEMS_WITH_HOOKS = 8
     MAX_TILES = 1024
+    MAX_TILES_OVERLAPPED = 256          # one round of 256 x 256 tiles
 
     def __init__(self):
         self.items = []
@@ -170,8 +170,15 @@ class _WgradQueue:
             except RuntimeError:                       # not inside an engine-driven backward pass: nothing will call back
                 self.flush()
                 return
-        if len(self.items) >= (self.MAX_PROBLEMS_WITH_HOOKS if grad_ready_hooks else self.MAX_PROBLEMS) or self.tiles >= self.MAX_TILES:
+        if len(self.items) >= self.MAX_PROBLEMS or self.tiles >= (self.MAX_TILES_OVERLAPPED if self._overlapping() else self.MAX_TILES):
             self.flush()
+
+    @staticmethod
+    def _overlapping():
+        if not grad_ready_hooks:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def _end_of_backward(self):
         self._cb = False
