@@ -151,7 +151,7 @@ class _WgradQueue:
     or a gradient norm reads the arena.  With gradient-ready hooks registered in a job of more than one rank (data-parallel bucket
     exchange) a group leaves as soon as it fills one round of the chip, so that buckets still go out during the backward."""
     enabled = os.environ.get("VMC_WGRAD_GROUP", "1") != "0"       # builder A/B switch
-    MAX_PROBLEMS = 28
+    MAX_PROBLEMS = ops.WGRAD_GROUP_MAX      # 32: the 30 linears of a 4-layer TFAM step leave as one launch (480 tiles = 1.9 rounds)
     MAX_TILES = 1024
     MAX_TILES_OVERLAPPED = 256          # one round of 256 x 256 tiles
 
