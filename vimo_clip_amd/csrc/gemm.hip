@@ -70,12 +70,20 @@ __device__ __forceinline__ void ring_wait_vm() {
 // NS == 2: the two-stage loop above.  NS > 2: an NS-stage LDS ring with NS-1 K tiles in flight and counted vmcnt --
 // for the latency-bound small problems (few workgroups per CU, e.g. the 256-row tail of a large GEMM), where one
 // exposed L2/HBM round trip per K tile is the whole run time.
-template <typename T, int ACT, int MT, int WM, int WN, int NS = 2>
-__global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
+// KS > 1 (ring variant only): KS groups of WM x WN waves share one output tile and split its K tiles between them -- group s takes
+// K tiles s, s + KS, ... through its own NS-stage ring -- and their accumulators are summed through LDS in the fixed order
+// 0, 1, .., KS-1 before the one epilogue (deterministic).  For the problems whose run time is ONE tile's dependent K chain (the
+// 256-row tails of the encoder's GEMMs: 16 .. 64 K tiles on 128 .. 256 workgroups): the chain is KS times shorter and KS times
+// more K tiles are in flight.
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1>
+__global__ void __launch_bounds__(64 * WM * WN * KS) gemm_kernel(const GemmArgs g) {
   using Cfg = GemmCfg<MT, WM, WN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(KS == 1 || NS > 2, "K-slice groups run the ring loop");
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-  const int tid = threadIdx.x;
+  const int ks = KS > 1 ? (int)threadIdx.x / Cfg::NT : 0;          // this thread's K-slice group
+  const int tid = KS > 1 ? (int)threadIdx.x - ks * Cfg::NT : (int)threadIdx.x;
+  char* const smem = smem_all + (KS > 1 ? ks * NS * Cfg::STAGE : 0);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -123,18 +131,22 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   const int nkt_all = g.K / 64;
   const int per_slice = (nkt_all + g.k_slices - 1) / g.k_slices;
   const int kt0 = blockIdx.y * per_slice;
-  const int nkt = min(nkt_all, kt0 + per_slice) - kt0;
-  if (nkt <= 0) return;
+  const int nkt_slice = min(nkt_all, kt0 + per_slice) - kt0;
+  if (nkt_slice <= 0) return;
+  // K-slice groups: group ks owns K tiles ks, ks + KS, ... of the range; every group runs the loop (and its barriers) as often as
+  // group 0, a group without a tile in the last round skips its DMA and MFMAs
+  const int nkt = KS > 1 ? (nkt_slice - ks + KS - 1) / KS : nkt_slice;
+  const int nkt_loop = KS > 1 ? (nkt_slice + KS - 1) / KS : nkt_slice;
 #pragma unroll
-  for (int i = 0; i < Cfg::A_ITERS; ++i) a_src[i] += (size_t)kt0 * 128;
+  for (int i = 0; i < Cfg::A_ITERS; ++i) a_src[i] += (size_t)(kt0 + ks) * 128;
 #pragma unroll
-  for (int i = 0; i < Cfg::B_ITERS; ++i) b_src[i] += (size_t)kt0 * 128;
+  for (int i = 0; i < Cfg::B_ITERS; ++i) b_src[i] += (size_t)(kt0 + ks) * 128;
   if constexpr (NS > 2) {
     constexpr int LOADS = Cfg::A_ITERS + Cfg::B_ITERS;      // LDS-DMA instructions per thread per stage
     static_assert(LOADS * (NS - 2) <= 63, "vmcnt field");
     auto stage_in = [&](int t) {
       char* dst = smem + (t % NS) * Cfg::STAGE;
-      const size_t koff = (size_t)t * 128;
+      const size_t koff = (size_t)t * 128 * KS;
 #pragma unroll
       for (int i = 0; i < Cfg::A_ITERS; ++i)
         __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(a_src[i] + koff), (VMC_LDS void*)(dst + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
@@ -146,9 +158,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
       if (t < nkt) stage_in(t);
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < nkt_loop; ++kt) {
       // stage kt must have landed; up to NS-2 younger stages may stay in flight
-      const int younger = min(NS - 2, nkt - 1 - kt);
+      const int younger = max(0, min(NS - 2, nkt - 1 - kt));
       if (younger >= NS - 2) ring_wait_vm<LOADS * (NS - 2)>();
       else if (NS > 3 && younger == NS - 3) ring_wait_vm<LOADS * (NS - 3 > 0 ? NS - 3 : 0)>();
       else if (NS > 4 && younger == NS - 4) ring_wait_vm<LOADS * (NS - 4 > 0 ? NS - 4 : 0)>();
@@ -156,6 +168,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
       __builtin_amdgcn_s_barrier();            // every wave sees stage kt and is done reading stage kt-1 ...
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NS - 1 < nkt) stage_in(kt + NS - 1);   // ... whose ring slot the new DMA overwrites
+      if (KS > 1 && kt >= nkt) continue;       // this group has no K tile in the last round (the barrier above is still taken)
       const uint32_t base = (uint32_t)(uintptr_t)(const VMC_LDS char*)(smem + (kt % NS) * Cfg::STAGE);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -200,6 +213,28 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   }
   }  // NS == 2
 
+  if constexpr (KS > 1) {      // sum the groups' accumulators in the order 0, 1, .., KS-1 (group 0 keeps the result and runs the epilogue)
+    __syncthreads();           // every group is done with its ring: the exchange buffer aliases it
+    float4* const xch = (float4*)smem_all;                              // [KS-1][Cfg::NT threads][MT*4] float4
+    if (ks > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          xch[((size_t)(ks - 1) * (MT * 4) + mt * 4 + nt) * Cfg::NT + tid] = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int s = 0; s < KS - 1; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float4 v = xch[((size_t)s * (MT * 4) + mt * 4 + nt) * Cfg::NT + tid];
+          acc[mt][nt][0] += v.x; acc[mt][nt][1] += v.y; acc[mt][nt][2] += v.z; acc[mt][nt][3] += v.w;
+        }
+  }
   // ---- epilogue: lane owns C[row][col0 .. col0+15] for each mt ----
   const int col0 = n0 + wn * 64 + 16 * q;
   if (g.k_slices > 1) {   // split-K: slice s writes its partial tile into slab s of the workspace (plain 16-byte stores)
@@ -273,11 +308,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(const GemmArgs g) {
   }
 }
 
-template <typename T, int ACT, int MT, int WM, int WN, int NS = 2>
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1>
 static int launch_cfg(GemmArgs& g, hipStream_t stream) {
   using Cfg = GemmCfg<MT, WM, WN>;
-  auto kern = gemm_kernel<T, ACT, MT, WM, WN, NS>;
-  constexpr int LDS = NS * Cfg::STAGE;
+  auto kern = gemm_kernel<T, ACT, MT, WM, WN, NS, KS>;
+  constexpr int XCH = (KS - 1) * Cfg::NT * MT * 4 * 16;                 // accumulator exchange of the K-slice groups (aliases the rings)
+  constexpr int LDS = KS * NS * Cfg::STAGE > XCH ? KS * NS * Cfg::STAGE : XCH;
+  static_assert(LDS <= 160 * 1024, "LDS");
+  if (KS > 1 && g.k_slices > 1) return VMC_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -286,7 +324,7 @@ static int launch_cfg(GemmArgs& g, hipStream_t stream) {
   }
   g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
   g.tiles_n = (g.N + Cfg::BN - 1) / Cfg::BN;
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.k_slices), dim3(Cfg::NT), LDS, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.k_slices), dim3(Cfg::NT * KS), LDS, stream, g);
   VMC_CHECK_LAUNCH();
   return 0;
 }
@@ -317,7 +355,21 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
   // from L2, so a long K chain on few workgroups is bound by that: when 64-row tiles give at most 128 workgroups (the 256-row tail
   // of c_proj: 4 x 16), 32-row tiles put twice as many CUs on it (same per-row arithmetic and K order: same bits; 27.3 -> 21.8 us at
   // K = 4096, 9.6 -> 7.9 us at K = 1024; 16-row single-wave tiles were slower again: 25.5 / 8.8 us).
-  if ((long)((g.M + 63) / 64) * ((g.N + 63) / 64) <= 128 && g.K >= 1024) return launch_cfg<T, ACT, 1, 2, 1, 4>(g, stream);
+  // K >= 1024 on at most one workgroup per CU is ONE tile's dependent K chain: K-slice groups inside the workgroup (gemm_kernel's KS)
+  // shorten it.  Measured on the encoder's 256-row tails (us, KS = 1 -> routed): out_proj 8.5 -> 6.7 and c_proj (K = 4096) 22.8 -> 15.4
+  // with four groups on 3-stage rings over 32-row tiles; qkv 10.6 -> 8.4 and c_fc 11.2 -> 9.6 with two groups on 4-stage rings over 64^2
+  // tiles; two groups / four stages on the 32-row tiles and two groups / three stages on 64^2 were slower (7.9 / 20.4, 8.7 / 9.7);
+  // 128 x 768 x 2048 (TFAM ffn.3 at B = 8, per-op path) 12.5 -> 8.2; encoder step 40.42 -> 40.07 ms (+0.9 %).  NOT routed by default
+  // (VMC_GEMM_KS=1 turns it on): the groups sum the K tiles in another order than the persistent kernel, so a row's bits would depend
+  // on whether it falls into a GEMM's 256-row tail -- the encoder's outputs are bit-identical under any batch split today
+  // (tests/test_gpu_encoder.py), and 0.9 % does not buy that back.
+  static const bool ks_on = getenv("VMC_GEMM_KS") && atoi(getenv("VMC_GEMM_KS")) != 0;
+  const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  if (t64 <= 128 && g.K >= 1024) {
+    if (ks_on && g.k_slices == 1) return launch_cfg<T, ACT, 1, 2, 1, 3, 4>(g, stream);
+    return launch_cfg<T, ACT, 1, 2, 1, 4>(g, stream);
+  }
+  if (ks_on && g.K >= 1024 && g.k_slices == 1 && t64 <= 256) return launch_cfg<T, ACT, 2, 2, 1, 4, 2>(g, stream);
   return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);
 }
 
