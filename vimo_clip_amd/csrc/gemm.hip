@@ -346,6 +346,9 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
       case 6: return launch_cfg<T, ACT, 4, 2, 2>(g, stream);         // 128 x 128, two stages (today's mid-size kernel)
       case 7: return launch_cfg<T, ACT, 4, 2, 1, 6>(g, stream);      // 128 x 64, 6-stage ring
       case 8: return launch_cfg<T, ACT, 2, 2, 2, 6>(g, stream);      // 64 x 128, 6-stage ring
+      case 9: return launch_cfg<T, ACT, 8, 2, 2>(g, stream);         // 256 x 128, two stages
+      case 10: return launch_cfg<T, ACT, 8, 2, 2, 3>(g, stream);     // 256 x 128, 3-stage ring
+      case 11: return launch_cfg<T, ACT, 4, 2, 4>(g, stream);        // 128 x 256, two stages
       default: break;
     }
   }
