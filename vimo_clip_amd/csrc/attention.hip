@@ -613,7 +613,56 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
   const size_t qrow0 = (size_t)b * Tq, krow0 = (size_t)b * Tk;
 
   // ---- stage Q, dO, K, V (zero padding rows); delta and lse ----
-  for (int idx = tid; idx < TQP * CH; idx += nthr) {
+  // ONE exposed memory round trip: every global load of the prologue (the first PF chunks per thread of each image -- all of them for
+  // the shapes this kernel sees: Tq, Tk <= 64 -- the O chunks and the lse of the delta rows) is issued before the first LDS write;
+  // as four run-time loops (stage Q | dO, stage K | V, delta from O and dO re-read from global) the prologue was five dependent
+  // round trips, most of a 13 us workgroup at ViT-B/32 (N = 50) and of the 7.7 us launch of a 16-token TFAM clip.
+  constexpr int PF = 4;
+  uint4 rq[PF], rdo[PF], rk[PF], rv[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int idx = tid + i * nthr, row = idx / CH, c = idx % CH;
+    rq[i] = rdo[i] = rk[i] = rv[i] = make_uint4(0, 0, 0, 0);
+    if (idx < TQP * CH && row < Tq) {
+      rq[i] = *(const uint4*)(qp + (qrow0 + row) * ldq + h * DH + c * 8);
+      rdo[i] = *(const uint4*)(dop + (qrow0 + row) * ldo + h * DH + c * 8);
+    }
+    if (idx < TKP * CH && row < Tk) {
+      rk[i] = *(const uint4*)(kp + (krow0 + row) * ldk + h * DH + c * 8);
+      rv[i] = *(const uint4*)(vp + (krow0 + row) * ldv + h * DH + c * 8);
+    }
+  }
+  // delta = rowsum(dO * O): four lanes per row (column chunks c = 8 part, 8 part + 32, ...), summed by two shuffles; O from global
+  // (prefetched here), dO from its LDS image after the first barrier
+  constexpr int DPF = 2;                                  // delta items per thread held in registers (TQP * 4 <= DPF * nthr)
+  uint4 ro[DPF][KK];
+  float rl[DPF];
+#pragma unroll
+  for (int u = 0; u < DPF; ++u) {
+    const int item = tid + u * nthr, row = item >> 2, part = item & 3;
+    rl[u] = 0.f;
+#pragma unroll
+    for (int m = 0; m < KK; ++m) ro[u][m] = make_uint4(0, 0, 0, 0);
+    if (item < TQP * 4 && row < Tq) {
+#pragma unroll
+      for (int m = 0; m < KK; ++m)
+        if (8 * part + 32 * m < DH) ro[u][m] = *(const uint4*)(op + (qrow0 + row) * ldo + h * DH + 8 * part + 32 * m);
+      if (part == 0) rl[u] = lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int idx = tid + i * nthr, row = idx / CH, c = idx % CH;
+    if (idx < TQP * CH) {
+      *(uint4*)(q_lds + row * RS + c * 16) = rq[i];
+      *(uint4*)(do_lds + row * RS + c * 16) = rdo[i];
+    }
+    if (idx < TKP * CH) {
+      *(uint4*)(k_lds + row * RS + c * 16) = rk[i];
+      *(uint4*)(v_lds + row * RS + c * 16) = rv[i];
+    }
+  }
+  for (int idx = tid + PF * nthr; idx < TQP * CH; idx += nthr) {        // longer sequences: the rest chunk by chunk
     const int row = idx / CH, c = idx % CH;
     uint4 a = make_uint4(0, 0, 0, 0), d = a;
     if (row < Tq) {
@@ -623,7 +672,7 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
     *(uint4*)(q_lds + row * RS + c * 16) = a;
     *(uint4*)(do_lds + row * RS + c * 16) = d;
   }
-  for (int idx = tid; idx < TKP * CH; idx += nthr) {
+  for (int idx = tid + PF * nthr; idx < TKP * CH; idx += nthr) {
     const int row = idx / CH, c = idx % CH;
     uint4 a = make_uint4(0, 0, 0, 0), d = a;
     if (row < Tk) {
@@ -633,24 +682,24 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
     *(uint4*)(k_lds + row * RS + c * 16) = a;
     *(uint4*)(v_lds + row * RS + c * 16) = d;
   }
-  // delta = rowsum(dO * O): four lanes per row (column chunks c = part, part + 4, ...), summed by two shuffles -- sixteen threads walking
-  // a whole row each left the other 240 waiting at the barrier (T = 16: the TFAM shapes)
-  for (int item = tid; item < TQP * 4; item += nthr) {
+  __syncthreads();
+  auto delta_item = [&](int item, const uint4 (&ov)[KK], float l2) {
     const int row = item >> 2, part = item & 3;
     float dl = 0.f;
     if (row < Tq) {
-      const uint16_t* o = op + (qrow0 + row) * ldo + h * DH;
-      const uint16_t* d = dop + (qrow0 + row) * ldo + h * DH;
 #pragma unroll
-      for (int c = 8 * part; c < DH; c += 32) {
-        const uint4 ow = *(const uint4*)(o + c), dw = *(const uint4*)(d + c);
-        const uint32_t oa[4] = {ow.x, ow.y, ow.z, ow.w}, da[4] = {dw.x, dw.y, dw.z, dw.w};
+      for (int m = 0; m < KK; ++m) {
+        const int c = 8 * part + 32 * m;
+        if (c < DH) {
+          const uint4 ow = ov[m], dw = *(const uint4*)(do_lds + row * RS + c * 2);
+          const uint32_t oa[4] = {ow.x, ow.y, ow.z, ow.w}, da[4] = {dw.x, dw.y, dw.z, dw.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float o0, o1, d0, d1;
-          unpack2<T>(oa[j], o0, o1);
-          unpack2<T>(da[j], d0, d1);
-          dl += o0 * d0 + o1 * d1;
+          for (int j = 0; j < 4; ++j) {
+            float o0, o1, d0, d1;
+            unpack2<T>(oa[j], o0, o1);
+            unpack2<T>(da[j], d0, d1);
+            dl += o0 * d0 + o1 * d1;
+          }
         }
       }
     }
@@ -658,8 +707,19 @@ __global__ void __launch_bounds__(256, 3) attn_bwd_mfma_kernel(const uint16_t* _
     dl += __shfl_xor(dl, 2, 64);
     if (part == 0) {
       del_s[row] = dl;
-      lse_s[row] = row < Tq ? lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f : 0.f;
+      lse_s[row] = l2;
     }
+  };
+#pragma unroll
+  for (int u = 0; u < DPF; ++u)
+    if (tid + u * nthr < TQP * 4) delta_item(tid + u * nthr, ro[u], rl[u]);
+  for (int item = tid + DPF * nthr; item < TQP * 4; item += nthr) {      // longer sequences
+    const int row = item >> 2, part = item & 3;
+    uint4 ov[KK];
+#pragma unroll
+    for (int m = 0; m < KK; ++m)
+      ov[m] = (row < Tq && 8 * part + 32 * m < DH) ? *(const uint4*)(op + (qrow0 + row) * ldo + h * DH + 8 * part + 32 * m) : make_uint4(0, 0, 0, 0);
+    delta_item(item, ov, (row < Tq && part == 0) ? lse[((size_t)b * H + h) * Tq + row] * 1.4426950408889634f : 0.f);
   }
   __syncthreads();
 
