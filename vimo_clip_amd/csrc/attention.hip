@@ -299,6 +299,14 @@ __global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restri
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const uint16_t* kb = kp + (size_t)b * Tk * ldk + h * DH;
   const uint16_t* vb = vp + (size_t)b * Tk * ldv + h * DH;
+  // the first query tile's fragments travel with the K / V staging loads (one exposed round trip instead of two); later tiles are
+  // fetched one tile ahead
+  uint4 qnext[KK];
+  {
+    const uint16_t* qr0 = qp + ((size_t)b * Tq + min(r, Tq - 1)) * ldq + h * DH;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qnext[kk] = *(const uint4*)(qr0 + (4 * kk + q) * 8);
+  }
   {
     constexpr int ITERS = (NKEYS * CH + 63) / 64;
     uint4 kreg[ITERS], vreg[ITERS];
@@ -335,10 +343,14 @@ __global__ void __launch_bounds__(64) attn_small_kernel(const uint16_t* __restri
   const uint4 ones = make_uint4(T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR, T::ONE_PAIR);
   for (int qt = 0; qt * 16 < Tq; ++qt) {
     const int qrow = qt * 16 + r;
-    const uint16_t* qr = qp + ((size_t)b * Tq + min(qrow, Tq - 1)) * ldq + h * DH;
     uint4 qf[KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const uint4*)(qr + (4 * kk + q) * 8);
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = qnext[kk];
+    if ((qt + 1) * 16 < Tq) {
+      const uint16_t* qr = qp + ((size_t)b * Tq + min(qrow + 16, Tq - 1)) * ldq + h * DH;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) qnext[kk] = *(const uint4*)(qr + (4 * kk + q) * 8);
+    }
     f32x4 s[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
