@@ -438,6 +438,78 @@ def _ddp_graph_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _ddp_grouped_wgrad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vimo_clip_amd import autograd_ops, parallel
+    from vimo_clip_amd.losses import bce_with_logits_loss
+    from vimo_clip_amd.optim import GradArena
+    from vimo_clip_amd.TFAM.models import AMO_CLIP
+    dist.init_process_group("gloo")
+    try:
+        D, H, L, FF, C, B, T = 768, 8, 4, 2048, 140, 32, 16      # 512 token rows: the per-op path, every linear eligible for the groups
+        m = AMO_CLIP(d_model=D, nhead=H, num_layers=L, dim_feedforward=FF, num_classes=C, dropout=0.0, mlp_dropout=0.0, device="cuda").cuda().train()
+        m.load_state_dict(synth.tfam_state_dict(D, H, L, FF, C, 9), strict=True)
+        arena = GradArena(m.used_parameters())
+        rgb = synth.normal(100 * rank, "r", (B, T, D)).cuda()
+        mot = synth.normal(100 * rank, "m", (B, T, D)).cuda()
+        y = synth.multi_hot_labels(100 * rank, "y", B, C).cuda()
+        grads, flushes = {}, {}
+        was = autograd_ops.wgrad_queue.enabled
+        real_flush = autograd_ops.wgrad_queue.flush
+        for grouped in (False, True):
+            autograd_ops.grad_ready_hooks.clear()
+            autograd_ops.wgrad_queue.enabled = grouped
+            red = parallel.GradientAllReducer(arena.flat_grad, bucket_bytes=4 << 20).attach(arena)
+            n = [0]
+
+            def counting_flush():
+                n[0] += bool(autograd_ops.wgrad_queue.items)
+                real_flush()
+            autograd_ops.wgrad_queue.flush = counting_flush
+            arena.flat_grad.fill_(7.0)
+            for _ in range(2):                                   # the first step teaches the reducer its report counts
+                bce_with_logits_loss(m(rgb, mot), y).backward()
+                scale = red.all_reduce()
+            torch.cuda.synchronize()
+            grads[grouped] = (arena.flat_grad * scale).cpu()
+            flushes[grouped] = n[0]
+            red.detach()
+        autograd_ops.wgrad_queue.flush = real_flush
+        autograd_ops.wgrad_queue.enabled = was
+        worst = 0.0
+        for p, o in zip(arena.params, arena.offsets):
+            a, b = grads[False][o:o + p.numel()], grads[True][o:o + p.numel()]
+            worst = max(worst, (a - b).abs().max().item() / max(1e-6, a.abs().max().item()))
+        q.put((rank, worst, flushes[True], float(grads[True].double().abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_weight_gradients_under_data_parallel_hooks_two_ranks_one_gpu():
+    """The weight-gradient groups with a bucket reducer attached in a 2-rank job: groups leave during the backward (a round of tiles at a
+    time: several flushes per backward, not one), the reducer sees every parameter as often as without grouping (its buckets complete),
+    the averaged gradients equal the ungrouped run and are identical on both ranks."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_grouped_wgrad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] <= 2e-4 for r in res), res
+    assert all(r[2] >= 4 for r in res), res                     # two backward passes, at least two groups each
+    assert res[0][3] == res[1][3], res
+
+
 def test_two_graph_data_parallel_step_two_ranks_one_gpu():
     """under data parallelism the small-batch step is forward/backward graph -> gradient exchange -> optimiser
     graph (graphs.GraphedTrainStep(exchange=, opt_fn=)) instead of the host-bound eager step.  Two ranks with different data and
