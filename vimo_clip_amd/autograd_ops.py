@@ -158,18 +158,21 @@ class _WgradQueue:
     def __init__(self):
         self.items = []
         self.tiles = 0
-        self._cb = False
+        self._task = -1                 # autograd graph task (one per backward pass) whose end-of-pass callback is registered
 
     def push(self, dz, x, out, db, params):
+        task = torch._C._current_graph_task_id()
+        if task != self._task:
+            # first problem of a new backward pass.  Anything still parked belongs to a pass that raised before its callback ran:
+            # its slots are written again by this pass (two writers in one launch would race), so it is dropped
+            self.items, self.tiles, self._task = [], 0, task
+            if task >= 0:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         self.items.append((dz, x, out, db, params))
         self.tiles += ((dz.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256)
-        if not self._cb:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
-                self._cb = True
-            except RuntimeError:                       # not inside an engine-driven backward pass: nothing will call back
-                self.flush()
-                return
+        if task < 0:                                   # not inside an engine-driven backward pass: nothing will call back
+            self.flush()
+            return
         if len(self.items) >= self.MAX_PROBLEMS or self.tiles >= (self.MAX_TILES_OVERLAPPED if self._overlapping() else self.MAX_TILES):
             self.flush()
 
@@ -181,7 +184,7 @@ class _WgradQueue:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def _end_of_backward(self):
-        self._cb = False
+        self._task = -1
         self.flush()
 
     def flush(self):
