@@ -354,6 +354,29 @@ def tfam_extras(dev, rank, world, cdt):
     out["adamw_roofline"] = {"bound": "hbm", "achieved": round(bytes_adam / t_adam / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(bytes_adam / t_adam / 8e12, 4), "params": arena.numel,
                              "note": "133 MB of state fits the 256 MiB Infinity Cache: MALL-resident, not an HBM-only figure"}
+    # the same step as ModelTrainer(use_graphs=True) runs it under data parallelism: forward + backward as one hipGraph, the bucket
+    # exchange (eager), AdamW + copy refresh as a second graph (graphs.GraphedTrainStep(exchange=, opt_fn=)); the eager figure above is
+    # bound by the host's launch rate
+    try:
+        from vimo_clip_amd.graphs import GraphedTrainStep
+        from vimo_clip_amd.losses import loss_and_grad
+        opt.enable_device_state(base_seed=rank)
+        m.use_device_seeds(opt)
+        red2 = GradientAllReducer(arena.flat_grad).attach(arena, register=False)
+
+        def fwd_bwd(a, b_, c, d):
+            opt.tick()
+            o = m(a, b_, mask_rgb=c, mask_flow=c)
+            loss, dl = loss_and_grad(bce_with_logits_loss, o, d)
+            o.backward(dl)
+            return loss
+
+        g2 = GraphedTrainStep(fwd_bwd, opt, exchange=red2.all_reduce, opt_fn=opt.step)
+        t2 = _time_step_dist(lambda: g2(rgb, mot, mk, y), 10, dev, world)
+        out["tfam_train_ms_per_step_two_graph"] = round(1e3 * t2, 3)
+        out["tfam_train_clips_per_s_two_graph"] = round(B * world / t2, 1)
+    except Exception as e:      # noqa: BLE001
+        out["tfam_train_ms_per_step_two_graph"] = f"error: {type(e).__name__}: {e}"
     if world == 1:
         try:
             out["tfam_train_small_batch"] = tfam_small_batch_train(dev, cdt, m)
