@@ -75,10 +75,14 @@ __device__ __forceinline__ void ring_wait_vm() {
 // 0, 1, .., KS-1 before the one epilogue (deterministic).  For the problems whose run time is ONE tile's dependent K chain (the
 // 256-row tails of the encoder's GEMMs: 16 .. 64 K tiles on 128 .. 256 workgroups): the chain is KS times shorter and KS times
 // more K tiles are in flight.
-template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1>
+// U > 1 (ring variant, KS == 1): U consecutive K tiles per barrier -- their fragments are all read before ONE lgkmcnt wait and the
+// MFMAs then run in the unchanged K order (same bits as U = 1): the loop of a small tile is a barrier, a vmcnt wait and two LDS round
+// trips per 64-deep K tile, which is what a latency-bound launch consists of.
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1, int U = 1>
 __global__ void __launch_bounds__(64 * WM * WN * KS) gemm_kernel(const GemmArgs g) {
   using Cfg = GemmCfg<MT, WM, WN>;
   static_assert(KS == 1 || NS > 2, "K-slice groups run the ring loop");
+  static_assert(U == 1 || (KS == 1 && NS > U + 1), "multi-tile steps: ring of more than U + 1 slots, no K-slice groups");
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
   const int ks = KS > 1 ? (int)threadIdx.x / Cfg::NT : 0;          // this thread's K-slice group
@@ -155,6 +159,48 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) gemm_kernel(const GemmArgs 
         __builtin_amdgcn_global_load_lds((const VMC_GLOBAL void*)(b_src[i] + koff),
                                          (VMC_LDS void*)(dst + Cfg::A_BYTES + i * Cfg::NT * 16 + wave_lds), 16, 0, 0);
     };
+    if constexpr (U > 1) {
+      constexpr int F = NS - U;                 // K tiles in flight at the top of a step (nkt % U == 0: launcher)
+      static_assert(LOADS * (F - U > 0 ? F - U : 0) <= 63, "vmcnt field");
+#pragma unroll
+      for (int t = 0; t < F; ++t)
+        if (t < nkt) stage_in(t);
+      for (int kt = 0; kt < nkt; kt += U) {
+        // tiles kt .. kt+U-1 must have landed; the younger ones (a multiple of U, at most F - U) may stay in flight
+        const int younger = min(F - U, nkt - kt - U);
+        if (younger >= F - U) ring_wait_vm<LOADS * (F - U > 0 ? F - U : 0)>();
+        else if (F - 2 * U > 0 && younger >= F - 2 * U) ring_wait_vm<LOADS * (F - 2 * U > 0 ? F - 2 * U : 0)>();
+        else ring_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();            // every wave sees these tiles and is done reading the U before them ...
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (kt + F + u < nkt) stage_in(kt + F + u);      // ... whose ring slots the new DMAs overwrite
+        uint4 wf[U][2][4], xf[U][2][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t base = (uint32_t)(uintptr_t)(const VMC_LDS char*)(smem + ((kt + u) % NS) * Cfg::STAGE);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ring_read128<0>(wf[u][kk][nt], base + (uint32_t)woff[kk][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ring_read128<0>(xf[u][kk][mt], base + (uint32_t)(xoff[kk] + mt * 2048));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = T::mfma16(wf[u][kk][nt], xf[u][kk][mt], acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
       if (t < nkt) stage_in(t);
@@ -186,6 +232,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) gemm_kernel(const GemmArgs 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }  // U == 1
   } else {
   char* const buf0 = smem;
   char* const buf1 = smem + Cfg::STAGE;
@@ -308,10 +355,11 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) gemm_kernel(const GemmArgs 
   }
 }
 
-template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1>
+template <typename T, int ACT, int MT, int WM, int WN, int NS = 2, int KS = 1, int U = 1>
 static int launch_cfg(GemmArgs& g, hipStream_t stream) {
   using Cfg = GemmCfg<MT, WM, WN>;
-  auto kern = gemm_kernel<T, ACT, MT, WM, WN, NS, KS>;
+  auto kern = gemm_kernel<T, ACT, MT, WM, WN, NS, KS, U>;
+  if (U > 1 && (g.k_slices > 1 || (g.K / 64) % U != 0)) return VMC_E_ARG;
   constexpr int XCH = (KS - 1) * Cfg::NT * MT * 4 * 16;                 // accumulator exchange of the K-slice groups (aliases the rings)
   constexpr int LDS = KS * NS * Cfg::STAGE > XCH ? KS * NS * Cfg::STAGE : XCH;
   static_assert(LDS <= 160 * 1024, "LDS");
@@ -368,11 +416,21 @@ static int launch_shape(GemmArgs& g, hipStream_t stream) {
   // (tests/test_gpu_encoder.py), and 0.9 % does not buy that back.
   static const bool ks_on = getenv("VMC_GEMM_KS") && atoi(getenv("VMC_GEMM_KS")) != 0;
   const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  // K tiles per barrier (gemm_kernel's U; same K order, same bits).  Measured on the encoder's 256-row tails and the TFAM small-batch
+  // shapes (us, U = 1 -> 4 on an 8-slot ring): 10.5 -> 9.9 (qkv), 7.8 -> 7.0, 8.5 -> 7.7 (out_proj), 22.7 -> 20.1 (c_proj, K = 4096),
+  // 11.1 = 11.1 (c_fc), 128 x 768 x 2048 12.4 -> 10.8; U = 2 on six slots: no gain.  An 8-slot ring of 64^2 tiles is 128 KiB (one
+  // workgroup per CU), so only problems of at most one workgroup per CU take it.  VMC_GEMM_U=1 turns it off (builder A/B switch).
+  static const int mt_sw = getenv("VMC_GEMM_U") ? atoi(getenv("VMC_GEMM_U")) : 4;
+  const bool u_ok = g.k_slices == 1 && g.K >= 512 && t64 <= 256;
   if (t64 <= 128 && g.K >= 1024) {
     if (ks_on && g.k_slices == 1) return launch_cfg<T, ACT, 1, 2, 1, 3, 4>(g, stream);
+    if (mt_sw == 2 && u_ok && (g.K / 64) % 2 == 0) return launch_cfg<T, ACT, 1, 2, 1, 6, 1, 2>(g, stream);
+    if (mt_sw == 4 && u_ok && (g.K / 64) % 4 == 0) return launch_cfg<T, ACT, 1, 2, 1, 8, 1, 4>(g, stream);
     return launch_cfg<T, ACT, 1, 2, 1, 4>(g, stream);
   }
   if (ks_on && g.K >= 1024 && g.k_slices == 1 && t64 <= 256) return launch_cfg<T, ACT, 2, 2, 1, 4, 2>(g, stream);
+  if (mt_sw == 2 && u_ok && (g.K / 64) % 2 == 0) return launch_cfg<T, ACT, 2, 2, 1, 6, 1, 2>(g, stream);
+  if (mt_sw == 4 && u_ok && (g.K / 64) % 4 == 0) return launch_cfg<T, ACT, 2, 2, 1, 8, 1, 4>(g, stream);
   return launch_cfg<T, ACT, 2, 2, 1, 4>(g, stream);
 }
 
