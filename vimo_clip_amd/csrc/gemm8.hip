@@ -132,14 +132,19 @@ __device__ __forceinline__ void g8_nt_store(const uint4& o, uint16_t* dst) {
 // per-lane offset; the offset is laundered through an empty asm so that hipcc forms the four row offsets here instead of keeping
 // sixteen of them live across the K loop.  Output stores are non-temporal (the tensor, 400 .. 540 MB per ViT-L/14 launch, is
 // larger than the Infinity Cache and is read next by another kernel).
+// Column halves of the persistent 16x16x32 kernel are INTERLEAVED: B half nh holds the tile's columns 64 j + 32 nh + [0, 32), j = 0..3,
+// so a wave's two halves are the two 64-byte halves of the same 128-byte output line of every row (written one phase apart by the
+// same wave) instead of lines 256 bytes apart whose other halves come from the neighbouring wave.
+#define G8P_NH_BYTES 64u        /* byte offset of half 1 inside the wave's 128-byte row segment */
+#define G8P_NH_BIAS 128         /* the same in the fp32 bias image */
 template <typename T, int ACT, bool BIAS, bool ZOUT, int MH, int NH>
 __device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[4][2], char* ctile, char* ztile, uint32_t clane, uint32_t zlane,
                                                  uint32_t bias_ad) {
   float bv[8];
   if constexpr (BIAS) {
     uint4 braw[2];
-    lds_read128<512 * NH>(braw[0], bias_ad);
-    lds_read128<512 * NH + 16>(braw[1], bias_ad);
+    lds_read128<G8P_NH_BIAS * NH>(braw[0], bias_ad);
+    lds_read128<G8P_NH_BIAS * NH + 16>(braw[1], bias_ad);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     bv[0] = __uint_as_float(braw[0].x); bv[1] = __uint_as_float(braw[0].y); bv[2] = __uint_as_float(braw[0].z); bv[3] = __uint_as_float(braw[0].w);
@@ -159,12 +164,12 @@ __device__ __forceinline__ void g8p_fin_quadrant(const GemmArgs& g, f32x4 (&aq)[
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * nt + j] = aq[mt][nt][j] + bv[4 * nt + j];
     if constexpr (ZOUT)      // pre-activation side output for the backward (training)
-      *(uint4*)(ztile + (zl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * NH)) =
+      *(uint4*)(ztile + (zl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + G8P_NH_BYTES * NH)) =
           make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = g.alpha * apply_act<ACT>(v[j]);
     g8_nt_store(make_uint4(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])),
-                (uint16_t*)(ctile + (cl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + 256u * NH)));
+                (uint16_t*)(ctile + (cl + (uint32_t)(128 * MH + 16 * mt) * (uint32_t)g.ldc * 2u + G8P_NH_BYTES * NH)));
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) aq[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -478,10 +483,10 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
     stage_src_x(i * 512 + tid, row, ch);
     oa[i] = (uint32_t)(row * g.lda + ch * 8) * 2u;
     stage_src_w8(i * 512 + tid, row, ch);
-    ob[i] = (uint32_t)(row * g.ldw + ch * 8) * 2u;
+    ob[i] = (uint32_t)((64 * (row >> 5) + (row & 31)) * g.ldw + ch * 8) * 2u;        // half nh: W rows 64 j + 32 nh + [0, 32)
   }
-  const uint32_t HA = 128u * (uint32_t)g.lda * 2u, HB = 128u * (uint32_t)g.ldw * 2u;   // second half-tile (rows + 128)
-  const uint32_t TA = 2 * HA, TB = 2 * HB;                                              // one tile row / column panel
+  const uint32_t HA = 128u * (uint32_t)g.lda * 2u, HB = 32u * (uint32_t)g.ldw * 2u;    // second half-tile (A: rows + 128, W: rows + 32)
+  const uint32_t TA = 2 * HA, TB = 256u * (uint32_t)g.ldw * 2u;                         // one tile row / column panel
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((size_t)g.M * g.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.ldw * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? g.bias : (const float*)g.W), 0, g.N * 4, 0x00020000);
@@ -502,8 +507,8 @@ __global__ void __launch_bounds__(512, 2) gemm8p_kernel(const GemmArgs g) {
   // issued half-tiles (in-order counter) and expose their latency.  Each wave DMAs the 64 floats of its column quarter.
   char* const bias_lds = smem + 8 * G8_SLOT;
   const uint32_t bias_lane = (uint32_t)lane * 4u;
-  const uint32_t bias_ad0 = lds_addr(bias_lds) + (uint32_t)(32 * wn + 8 * q) * 4u;
-  const uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 32 * wn + 8 * q) * 2u;
+  const uint32_t bias_ad0 = lds_addr(bias_lds) + (uint32_t)(64 * wn + 8 * q) * 4u;
+  const uint32_t clane = ((uint32_t)(64 * wm + r) * (uint32_t)g.ldc + 64 * wn + 8 * q) * 2u;
   const uint32_t zlane = clane;     // the side output has the row stride of the output (launcher: ldz == ldc); one VGPR fewer
 
   const int nkt = g.K >> 6;   // even, >= 4 (checked by the launcher)
