@@ -2,6 +2,8 @@
 the C ABI via vimo_clip_amd.ops).  Integer-valued operands make the MFMA GEMM checks bit-exact."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -89,6 +91,40 @@ def test_linear_persistent_walk(ops, dtype, M, N, K, act):
             z = torch.zeros(M, N, device=DEV, dtype=dtype)
             y = ops.linear(ar, wr, bias=br, act=1, out_dtype=dtype, z_out=z)
             assert torch.equal(y, y_ref) and torch.equal(z, z_ref)
+
+
+def test_linear_k_slice_groups_in_a_subprocess():
+    """gemm_kernel's K-slice groups (VMC_GEMM_KS=1: measured, not routed by default -- DESIGN 3.1 / profiles/README.md) stay correct:
+    the switch is read once per process, so the check runs in a child process.  Integer operands: exact whatever the summation order;
+    the 256-row tail shapes of the encoder (32-row tiles with four groups, 64^2 tiles with two) with bias, QuickGELU and fp32 residual."""
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from vimo_clip_amd import ops
+g = torch.Generator().manual_seed(3)
+for (M, N, K, act, res32) in [(256, 1024, 1024, 0, True), (256, 1024, 4096, 0, True), (256, 3072, 1024, 0, False), (256, 4096, 1024, 3, False), (128, 768, 2048, 0, False)]:
+    for dt in (torch.bfloat16, torch.float16):
+        a = torch.randint(-1, 2, (M, K), generator=g).float()
+        w = torch.randint(-1, 2, (N, K), generator=g).float()
+        b = (torch.arange(N).float() % 7) - 3
+        z = a.cuda() @ w.cuda().t() + b.cuda()
+        if act == 3:
+            z = torch.relu(z)
+        assert z.abs().max().item() <= 256
+        if res32:
+            x0 = torch.randint(-8, 9, (M, N), generator=g).float().cuda()
+            out = ops.linear(a.cuda().to(dt), w.cuda().to(dt), bias=b.cuda(), out=x0.clone(), res=x0)
+            assert torch.equal(out, x0 + z), (M, N, K, dt)
+        else:
+            out = ops.linear(a.cuda().to(dt), w.cuda().to(dt), bias=b.cuda(), act=act, out_dtype=dt)
+            assert torch.equal(out.float(), z), (M, N, K, dt)
+print("k-slice groups ok")
+'''
+    env = dict(os.environ, VMC_GEMM_KS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "k-slice groups ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
