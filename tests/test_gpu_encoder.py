@@ -118,6 +118,23 @@ def test_class_query_attention_in_the_last_block_is_the_same_function(name):
         assert d <= 1e-6 * max(1.0, y_full.abs().max().item())
 
 
+def test_encoder_slices_on_two_streams_give_the_same_bits():
+    """VisionTransformer.slice_streams = 2: the frames of a pass as two slices on two streams (opt-in: +2 % frames/s on ViT-L/14 at 256
+    frames, profiles/README.md) -- frames are independent and both slices run the same kernels, so the embeddings are bit-identical;
+    the weight copies are cast before the fork (a cold cache must not race)."""
+    from vimo_clip_amd.autograd_ops import weights
+    c = mg.VIT_CASES[0]
+    m = _encoder(c, torch.bfloat16)
+    u8 = synth.randint_u8(5, "frames", (130, 3, 64, 64)).cuda()
+    ref = m.encode_frames_u8(u8)
+    m.slice_streams = 2
+    weights.clear()                                # cold cache: the fork must not read a copy before its cast has run
+    for _ in range(3):
+        assert torch.equal(m.encode_frames_u8(u8), ref)
+    m.slice_streams = 4                            # fewer than 64 frames per slice: falls back to one stream
+    assert torch.equal(m.encode_frames_u8(u8), ref)
+
+
 def test_encoder_chunking_and_batch_independence():
     c = mg.VIT_CASES[0]
     m = _encoder(c, torch.bfloat16)

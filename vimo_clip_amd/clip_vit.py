@@ -278,9 +278,52 @@ class VisionTransformer(nn.Module):
         from .preprocess import resize_center_crop_u8
         return resize_center_crop_u8(frames_u8, R, crop_mode, wrap_quirk)
 
+    def _warm_weight_copies(self, patch_mode: str):
+        """Every 16-bit compute copy the inference forward reads, cast on the CURRENT stream (before the forward forks into streams:
+        the cache is filled at enqueue time, so a second stream could otherwise read a copy whose cast kernel has not run yet)."""
+        self.patch_operands(patch_mode)
+        for i, blk in enumerate(self.transformer.resblocks):
+            pre = f"blk{i}."
+            self.w16(pre + "in_proj", blk.attn.in_proj_weight)
+            self.w16(pre + "out_proj", blk.attn.out_proj.weight)
+            self.w16(pre + "c_fc", blk.mlp.c_fc.weight)
+            self.w16(pre + "c_proj", blk.mlp.c_proj.weight)
+        self.w16("proj", self.proj, transposed=True)
+
+    @torch.no_grad()
+    def _encode_on_streams(self, frames_u8: torch.Tensor, wrap: bool, n: int) -> torch.Tensor:
+        """The frames of one pass as n slices on n streams: while one slice's kernel drains (the last round of a persistent GEMM walk,
+        the tail launch, a memory-bound pass that leaves the MFMA pipes idle) another slice's next kernel already runs.  Frames are
+        independent and every slice runs the same kernels: same bits as one stream (tests/test_gpu_encoder.py)."""
+        F = frames_u8.shape[0]
+        mode = "u8_exact" if self.exact_patch_embed else "plain"
+        self._warm_weight_copies(mode)
+        cur = torch.cuda.current_stream()
+        pool = getattr(self, "_slice_streams", None)
+        if pool is None or len(pool) < n:
+            pool = self._slice_streams = [torch.cuda.Stream() for _ in range(n)]
+        cuts = [F * k // n for k in range(n + 1)]
+        outs = []
+        for st, a, b in zip(pool, cuts[:-1], cuts[1:]):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                fr = frames_u8[a:b]
+                if self.exact_patch_embed:
+                    patches = ops.patches_u8_exact(fr, self.patch_size, self.compute_dtype, wrap)
+                else:
+                    patches = ops.preprocess_patches_u8(fr, self.patch_size, self.compute_dtype, wrap)
+                outs.append(self._encode_patches(patches, b - a, patch_mode=mode))
+        for st in pool[:n]:
+            cur.wait_stream(st)
+        return torch.cat(outs, dim=0)
+
     @torch.no_grad()
     def encode_frames_u8(self, frames_u8: torch.Tensor, wrap_quirk: bool = False, crop_mode: str = "torchvision") -> torch.Tensor:
         """[F,3,H,W] u8 -> [F,E] f32.  Resize/crop (when H,W != R), CLIP normalisation and patch extraction run on the GPU (K0)."""
+        n = int(getattr(self, "slice_streams", 1))
+        if n > 1 and frames_u8.is_cuda and 64 * n <= frames_u8.shape[0] <= self.frame_chunk:
+            fr, wrap = self.fit_frames_u8(frames_u8, wrap_quirk, crop_mode)
+            return self._encode_on_streams(fr, wrap, n)
         outs = []
         for s in range(0, frames_u8.shape[0], self.frame_chunk):
             fr, wrap = self.fit_frames_u8(frames_u8[s:s + self.frame_chunk], wrap_quirk, crop_mode)
