@@ -274,10 +274,11 @@ def test_attention_generic_masked(ops, dtype, B, H, Tq, Tk, dh):
 
 
 @pytest.mark.parametrize("dtype", DT16, ids=["bf16", "f16"])
-@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(3, 8, 16, 16, 96), (2, 4, 20, 33, 64), (2, 8, 16, 64, 96), (2, 2, 40, 200, 64)])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh", [(3, 8, 16, 16, 96), (2, 4, 20, 33, 64), (2, 8, 16, 64, 96), (2, 2, 40, 200, 64), (1, 2, 150, 197, 64)])
 def test_attention_with_probability_dropout(ops, dtype, B, H, Tq, Tk, dh):
     """Dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), training) in the MFMA kernels (short sequences;
-    the last case is a long one on the generic fp32 kernels): forward and the three gradients against torch autograd with the SAME
+    the long ones are past what the backward's prologue prefetches in registers: its chunk-by-chunk remainder loops for Q | dO,
+    K | V and the delta rows): forward and the three gradients against torch autograd with the SAME
     mask, which is vmc_dropout's counter-based mask on the flat (batch, head, query, key) index -- obtained by running vmc_dropout
     on a tensor of ones."""
     from vimo_clip_amd import autograd_ops as ag
